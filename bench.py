@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- depth-crops/sec of the hot path on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of 40 synthetic 128x128 crops per GPU, inputs
+resident in HBM before the timed region:
+  --mode train (default when the handle supports it): NYU S=2 F=128 J=14 B=40 train micro-step =
+        forward (batch-stat BatchReNorm, dropout) + loss + backward; every `sub_batch`-th step also
+        all-reduces the flat gradient over RCCL (N>1) and applies clip+Adam -- BASELINE.json config 3/4.
+  --mode infer: ICVL S=2 F=128 J=16 B=40 forward(eval) + vote -> xyz -- BASELINE.json config 2.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+HIP-event timed in a separate profiled pass over the same workload) and `cpu_baseline` (the CPU
+oracle restatement timed on the host cores, rank 0 / N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from densereg_amd.data.synthetic import DATASETS, make_crops  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--mode', choices=['train', 'infer'], default=os.environ.get('DR_BENCH_MODE', 'train'))
+    ap.add_argument('--batch', type=int, default=40)
+    ap.add_argument('--sub_batch', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(mode, cfg_tuple, B, dataset):
+    """The CPU oracle (PyTorch-CPU restatement of the reference graph, NOT TF1.3) on the host cores."""
+    from oracle import net, pose, train
+    from oracle.graph import NetConfig
+    S, F, J = cfg_tuple
+    cfg = NetConfig(S, F, J)
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    dm, poses, cfgs, coms, _ = make_crops(B, dataset, seed=999)
+    ndm = pose.norm_dm(dm, coms)
+    params = net.init_params(cfg, 7)
+    times = []
+    budget_s, t_start = 25.0, time.time()
+    it = 0
+    while it < 13 and (time.time() - t_start < budget_s or it < 2):
+        t0 = time.time()
+        if mode == 'infer':
+            ep = net.forward_eval(cfg, params, ndm)
+            pose.estimate_pose_mm(ep['hm_outs'][-1], ep['hm3_outs'][-1], ep['um_outs'][-1], ndm, cfgs, coms)
+        else:
+            train.loss_and_grads(cfg, params, ndm, poses, cfgs, coms)
+        dt = time.time() - t0
+        if it >= 1:                      # first iteration = warm-up
+            times.append(dt)
+        it += 1
+    med = float(np.median(times))
+    return {'value': B / med, 'unit': 'crops/s', 'cores': ncores, 'kind': 'port',
+            'sample': '%d timed iterations of one B=%d %s step on the CPU oracle (PyTorch-CPU fp32, oneDNN), median'
+                      % (len(times), B, 'fwd(eval)+vote' if mode == 'infer' else 'fwd+bwd')}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    assert world == args.gpus or world == 1, 'launch N>1 through torch.distributed.run'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    from densereg_amd import _lib
+    from densereg_amd.engine import Engine
+    from densereg_amd.parallel import DataParallelTrainer
+
+    mode = args.mode
+    dataset = 'nyu' if mode == 'train' else 'icvl'
+    J = DATASETS[dataset]['jnt_num']
+    S, F, B = 2, 128, args.batch
+    eng = Engine(S, F, J, 128, 3, B, local, training=(mode == 'train'))
+
+    # random-init weights of the named architecture (values are irrelevant to dense conv speed)
+    rng = np.random.default_rng(7)
+    params = {}
+    for name, shape, _ in eng.param_infos():
+        leaf = name.rsplit('/', 1)[1]
+        if leaf == 'weights':
+            params[name] = (rng.standard_normal(shape) * np.sqrt(2.0 / (shape[0] * shape[1] * shape[2]))).astype(np.float32)
+        elif leaf in ('gamma', 'moving_variance', 'r_max'):
+            params[name] = np.ones(shape, np.float32)
+        else:
+            params[name] = np.zeros(shape, np.float32)
+    eng.load_params(params)
+
+    dm, poses, cfgs, coms, _ = make_crops(B, dataset, seed=20240, rank=rank)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_dm_mm, d_pose, d_cfg, d_com = t(dm), t(poses), t(cfgs), t(coms)
+    d_dm = eng.norm_dm(d_dm_mm, d_com)
+    xyz = eng.new(B, 3 * J)
+    trainer = DataParallelTrainer(eng, dataset=dataset, sub_batch=args.sub_batch, dist=dist) if mode == 'train' else None
+
+    def step(i):
+        if mode == 'infer':
+            eng.infer(d_dm, d_cfg, d_com, out=xyz)
+        else:
+            trainer.micro_step(d_dm, d_pose, d_cfg, d_com, seed=i)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline leg: separate profiled pass (events around every op), same workload ------------
+    roof = None
+    if not args.no_profile:
+        eng.h.profile(True)
+        nprof = max(2, min(5, args.steps))
+        for i in range(nprof):
+            step(1000 + i)
+        stats = eng.h.profile_read()
+        eng.h.profile(False)
+        convs = [s for s in stats if s['name'].startswith('conv_') and s['flops'] > 0]
+        if convs:
+            dom = max(convs, key=lambda s: s['total_ms'])
+            ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+            roof = {'kernel': dom['name'], 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                    'launches_per_step': dom['launches'] / nprof, 'avg_launch_us': dom['total_ms'] * 1e3 / dom['launches'],
+                    'algorithmic_gflop_per_launch': dom['flops'] / dom['launches'] / 1e9,
+                    'share_of_step_time': dom['total_ms'] / max(sum(s['total_ms'] for s in stats), 1e-9),
+                    'all_kernels': {s['name']: {'ms_per_step': s['total_ms'] / nprof, 'launches': s['launches'] // nprof,
+                                                'tflops': (s['flops'] / (s['total_ms'] * 1e-3) / 1e12) if s['flops'] else None,
+                                                'gbs': (s['bytes'] / (s['total_ms'] * 1e-3) / 1e9) if s['bytes'] else None}
+                                    for s in stats}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(mode, (S, F, J), B, dataset)
+
+    if rank == 0:
+        crops = B * world * args.steps
+        out = {
+            'metric': 'depth-crops/sec %s, 2-stack fea=128 @128x128' % ('fwd+bwd' if mode == 'train' else 'fwd(eval)+vote'),
+            'value': crops / dt, 'unit': 'crops/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': ('%s S=2 F=128 J=%d B=%d/GPU 128x128 ' % (dataset.upper(), J, B)) +
+                       ('train micro-step fwd+loss+bwd, RCCL all-reduce + clip + Adam every %d steps' % args.sub_batch
+                        if mode == 'train' else 'forward(eval) + vote -> xyz mm'),
+                       'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                       'conv_gflop_per_crop_fwd': eng.conv_flops_per_crop() / 1e9},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,823 @@
+// densereg.cpp -- graph builder, parameter registry, executors and the C ABI (include/densereg.h).
+// Compiled by hipcc for gfx950 into libdensereg_hip.so (and, for CPU-side unit tests only, by a
+// host clang++ with -DDR_EMU against tests/hipemu).
+#include <algorithm>
+#include <cmath>
+#include <map>
+
+#include "conv_igemm.h"
+#include "kernels_misc.h"
+#include "net.h"
+#include "train_kernels.h"
+#include "vote.h"
+
+using namespace dr;
+
+static std::string g_create_err;
+
+#define DR_FAIL(h, code, ...)                                  \
+    do {                                                       \
+        char _b[512];                                          \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                 \
+        (h)->err = _b;                                         \
+        return (code);                                         \
+    } while (0)
+
+#define DR_CHECK_LAUNCH(h)                                                     \
+    do {                                                                       \
+        std::string _m;                                                        \
+        if (rt::last_error(&_m)) DR_FAIL(h, DR_E_DEVICE, "HIP error: %s (%s:%d)", _m.c_str(), __FILE__, __LINE__); \
+    } while (0)
+
+static inline int grid_for(long total, int block = 256, int cap = 256 * 8) {
+    long g = (total + block - 1) / block;
+    return (int)std::max<long>(1, std::min<long>(g, cap));
+}
+
+// ==============================================================================================
+// conv launcher
+// ==============================================================================================
+namespace dr {
+
+template <int BM, int BN, int WM, int WN>
+static void launch_cfg(const ConvParams& p, hipStream_t s) {
+    const int M = p.B * p.H * p.W;
+    dim3 grid(dr_ceil_div(M, BM), dr_ceil_div(p.Np, BN));
+    DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, p);
+}
+
+// tile shape for a problem (shared by the launcher and the profiler labels)
+int conv_tile_id(const ConvParams& p) {
+    const int M = p.B * p.H * p.W;
+    if (p.Np % 128 == 0) return KID_CONV_128x128;
+    if (p.Np % 64 == 0) return ((long)dr_ceil_div(M, 128) * (p.Np / 64) >= 512) ? KID_CONV_128x64 : KID_CONV_64x64;
+    return KID_CONV_128x32;
+}
+
+int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
+    if (p.x_cs % 4 || p.x_coff % 4 || p.Kp % 16 || p.Np % 32) return -1;
+    switch (conv_tile_id(p)) {
+        case KID_CONV_128x128: launch_cfg<128, 128, 2, 2>(p, s); break;
+        case KID_CONV_128x64: launch_cfg<128, 64, 2, 2>(p, s); break;
+        case KID_CONV_64x64: launch_cfg<64, 64, 2, 2>(p, s); break;
+        default: launch_cfg<128, 32, 4, 1>(p, s); break;
+    }
+    return 0;
+}
+
+// RAII profiling scope: two events around the launches of one op (only when profiling is on)
+struct ProfScope {
+    dr_handle* h; hipStream_t s; ProfRecord r;
+    ProfScope(dr_handle* h_, hipStream_t s_, int kid, double flops, double bytes) : h(h_), s(s_) {
+        if (!h->profiling) return;
+        r.kid = kid; r.flops = flops; r.bytes = bytes;
+        r.a = rt::event_create(); r.b = rt::event_create();
+        rt::event_record(r.a, s);
+    }
+    ~ProfScope() {
+        if (!h->profiling) return;
+        rt::event_record(r.b, s);
+        h->prof.push_back(r);
+    }
+};
+
+}  // namespace dr
+
+// ==============================================================================================
+// small device helpers for parameters
+// ==============================================================================================
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float* wp, int taps, int Cin, int Cout,
+                                                           int Kp, int Np) {
+    const long total = (long)taps * Kp * Np;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = int(i % Np);
+        const int k = int((i / Np) % Kp);
+        const int t = int(i / ((long)Np * Kp));
+        wp[i] = (k < Cin && n < Cout) ? w[((long)t * Cin + k) * Cout + n] : 0.f;
+    }
+}
+
+// dgrad weights: wpT[t'][k=cout][n=cin] = w[taps-1-t'][cin][cout]
+__global__ __launch_bounds__(256) void pack_weights_T_kernel(const float* w, float* wpT, int taps, int Cin, int Cout,
+                                                             int KpT, int NpT) {
+    const long total = (long)taps * KpT * NpT;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = int(i % NpT);
+        const int k = int((i / NpT) % KpT);
+        const int t = int(i / ((long)NpT * KpT));
+        wpT[i] = (k < Cout && n < Cin) ? w[((long)(taps - 1 - t) * Cin + n) * Cout + k] : 0.f;
+    }
+}
+
+// eval-mode BatchReNorm fold (ops.py:173-180): scale = gamma*rsqrt(var+eps), shift = beta - mean*scale
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* beta, const float* gamma, const float* mm,
+                                                      const float* mv, float* scale, float* shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float inv = (1.0f / sqrtf(mv[c] + eps)) * gamma[c];
+        scale[c] = inv;
+        shift[c] = beta[c] - mm[c] * inv;
+    }
+}
+
+// ==============================================================================================
+// graph builder (network/um_v1.py)
+// ==============================================================================================
+namespace {
+
+struct Builder {
+    dr_handle* h;
+    int stem_count = 0, root_count = 0;
+    bool in_stem = false;
+
+    Tensor* new_tensor(int H, int W, int C, const char* tag) {
+        auto t = std::make_unique<Tensor>();
+        t->id = (int)h->tensors.size();
+        t->H = H; t->W = W; t->C = C; t->cs = dr_round_up(C, 4);
+        t->tag = tag;
+        h->tensors.push_back(std::move(t));
+        return h->tensors.back().get();
+    }
+    TView whole(Tensor* t) { return TView{t, 0, t->C}; }
+    TView slice(Tensor* t, int coff, int C) { return TView{t, coff, C}; }
+
+    std::string next_name() {
+        int& n = in_stem ? stem_count : root_count;
+        std::string base = n == 0 ? "Conv" : "Conv_" + std::to_string(n);
+        ++n;
+        return (in_stem ? std::string("hg_imgproc/") : std::string()) + base;
+    }
+
+    // creates the ConvLayer (name order = creation order); the op is appended by add_conv_op
+    int new_conv(int k, int stride, int cin, int cout, bool bn, bool relu, float wd, int H, int W) {
+        ConvLayer c;
+        c.name = next_name();
+        c.k = k; c.stride = stride; c.cin = cin; c.cout = cout; c.bn = bn; c.relu = relu; c.wd = wd;
+        c.H = H; c.W = W;
+        h->convs.push_back(c);
+        h->flops_per_crop += 2.0 * H * W * k * k * cin * cout;
+        return (int)h->convs.size() - 1;
+    }
+    void add_conv_op(int ci, TView in, TView out, TView res = TView(), bool masked = false, int dropout = -1) {
+        Op op;
+        op.kind = h->convs[ci].k == 7 ? OP_STEM : OP_CONV;
+        op.in = in; op.out = out; op.in2 = res; op.conv = ci; op.masked = masked; op.dropout = dropout;
+        h->ops.push_back(op);
+    }
+
+    // um_v1.py:18-48
+    TView residual(TView ins, int num_out, TView dst = TView(), bool masked = false) {
+        const int cin = ins.C;
+        if (num_out <= 0) num_out = cin;
+        const int half = cin / 2;
+        const int H = ins.t->H, W = ins.t->W;
+        const int k = h->cfg.kernel_size;
+        const int c1 = new_conv(1, 1, cin, half, true, true, 0.0005f, H, W);
+        const int c2 = new_conv(k, 1, half, half, true, true, 0.0005f, H, W);
+        const int c3 = new_conv(1, 1, half, num_out, true, true, 0.0005f, H, W);
+        int cs = -1;
+        if (num_out != cin) cs = new_conv(1, 1, cin, num_out, true, true, 0.0005f, H, W);
+        TView t1 = whole(new_tensor(H, W, half, "res.c1"));
+        TView t2 = whole(new_tensor(H, W, half, "res.c2"));
+        if (!dst.valid()) dst = whole(new_tensor(H, W, num_out, "res.out"));
+        add_conv_op(c1, ins, t1, TView(), masked);
+        add_conv_op(c2, t1, t2);
+        TView skip = ins;
+        if (cs >= 0) {
+            skip = whole(new_tensor(H, W, num_out, "res.skip"));
+            add_conv_op(cs, ins, skip, TView(), masked);
+        }
+        add_conv_op(c3, t2, dst, skip);
+        return dst;
+    }
+
+    TView pool(TView in, int k) {
+        const int Ho = (in.t->H + 1) / 2, Wo = (in.t->W + 1) / 2;
+        TView out = whole(new_tensor(Ho, Wo, in.C, "pool"));
+        Op op; op.kind = OP_POOL; op.in = in; op.out = out; op.pool_k = k;
+        h->ops.push_back(op);
+        return out;
+    }
+
+    // um_v1.py:51-69
+    TView hourglass(TView ins, int n, TView dst = TView()) {
+        TView upper1 = residual(ins, 0);
+        TView lower1 = pool(ins, h->cfg.kernel_size);
+        lower1 = residual(lower1, 0);
+        TView lower2 = n > 1 ? hourglass(lower1, n - 1) : lower1;
+        TView lower3 = residual(lower2, 0);
+        if (!dst.valid()) dst = whole(new_tensor(ins.t->H, ins.t->W, ins.C, "hg.out"));
+        Op op; op.kind = OP_UPADD; op.in = upper1; op.in2 = lower3; op.out = dst;
+        h->ops.push_back(op);
+        return dst;
+    }
+
+    void copy(TView src, TView dst) {
+        Op op; op.kind = OP_COPY; op.in = src; op.out = dst;
+        h->ops.push_back(op);
+    }
+
+    // um_v1.py:71-185
+    void detect_net() {
+        const dr_config& c = h->cfg;
+        const int F = c.num_fea, J = c.num_jnt, hw = c.in_hw, mh = hw / 4;
+        h->map_hw = mh;
+        const int num_resize = hw == 512 ? 6 : (hw == 256 ? 5 : 4);
+        Tensor* input = new_tensor(hw, hw, 1, "input");
+        input->needs_grad = false;
+        h->input = input;
+
+        in_stem = true;
+        const int conv1 = new_conv(7, 2, 1, 32, true, true, 0.0005f, hw / 2, hw / 2);
+        TView t_conv1 = whole(new_tensor(hw / 2, hw / 2, 32, "stem.conv1"));
+        add_conv_op(conv1, whole(input), t_conv1);
+        TView conv_2 = residual(t_conv1, 64);
+        TView pool_1 = pool(conv_2, 2);
+        TView conv_3 = residual(pool_1, 0);
+        TView hg_ins = residual(conv_3, F);
+        in_stem = false;
+
+        // uvd channels are written once per destination concat buffer
+        std::vector<Tensor*> LLU(c.num_stack), CMB(c.num_stack);
+        for (int s = 0; s < c.num_stack; ++s) {
+            LLU[s] = new_tensor(mh, mh, F + 3, "ll|uvd");
+            CMB[s] = new_tensor(mh, mh, 512 + 3, "comb|uvd");
+            Op op; op.kind = OP_UVD; op.in = whole(input);
+            op.uvd0 = slice(LLU[s], F, 3); op.uvd1 = slice(CMB[s], 512, 3);
+            h->ops.push_back(op);
+        }
+
+        for (int s = 0; s < c.num_stack; ++s) {
+            Tensor* A = new_tensor(mh, mh, F + 2 * J, "hg|hm|hm3");
+            TView hg_outs = hourglass(hg_ins, num_resize, slice(A, 0, F));
+            TView ll = residual(hg_outs, 0);
+            const int c_ll = new_conv(1, 1, F, F, true, true, 0.0005f, mh, mh);
+            TView ll2 = slice(LLU[s], 0, F);
+            add_conv_op(c_ll, ll, ll2);
+            const int c_hm = new_conv(1, 1, F, J, false, false, 0.0005f, mh, mh);
+            Tensor* HM = new_tensor(mh, mh, J, "hm_out");
+            add_conv_op(c_hm, ll2, whole(HM));
+            copy(whole(HM), slice(A, F, J));
+            TView hm3_in = residual(whole(LLU[s]), 128);
+            const int c_hm3 = new_conv(1, 1, 128, J, false, false, 0.0005f, mh, mh);
+            Tensor* HM3 = new_tensor(mh, mh, J, "hm3_out");
+            add_conv_op(c_hm3, hm3_in, whole(HM3));
+            copy(whole(HM3), slice(A, F + J, J));
+
+            Tensor* CAT = new_tensor(mh, mh, 512, "um_in|um_in_mask");
+            TView um_a = residual(whole(A), 256);
+            residual(um_a, 0, slice(CAT, 0, 256));
+            TView um_m = residual(whole(A), 256, TView(), /*masked=*/true);
+            residual(um_m, 0, slice(CAT, 256, 256));
+            residual(whole(CAT), 0, slice(CMB[s], 0, 512));
+
+            const int c_f1 = new_conv(1, 1, 515, 512, false, true, 0.0005f, mh, mh);
+            TView f1 = whole(new_tensor(mh, mh, 512, "um_full1"));
+            add_conv_op(c_f1, whole(CMB[s]), f1, TView(), false, s * 2 + 0);
+            const int c_f2 = new_conv(1, 1, 512, 512, false, true, 0.0005f, mh, mh);
+            TView f2 = whole(new_tensor(mh, mh, 512, "um_full2"));
+            add_conv_op(c_f2, f1, f2, TView(), false, s * 2 + 1);
+            const int c_um = new_conv(1, 1, 512, 3 * J, false, false, 0.0005f, mh, mh);
+            Tensor* UM = new_tensor(mh, mh, 3 * J, "um_out");
+            add_conv_op(c_um, f2, whole(UM));
+            h->hm.push_back(HM); h->hm3.push_back(HM3); h->um.push_back(UM);
+
+            if (s < c.num_stack - 1) {
+                Tensor* T = new_tensor(mh, mh, 5 * J, "hm|hm3|um");
+                copy(whole(HM), slice(T, 0, J));
+                copy(whole(HM3), slice(T, J, J));
+                copy(whole(UM), slice(T, 2 * J, 3 * J));
+                const int c_t = new_conv(1, 1, 5 * J, F, false, false, 0.f, mh, mh);
+                const int c_i = new_conv(1, 1, F, F, false, false, 0.f, mh, mh);
+                TView x1 = whole(new_tensor(mh, mh, F, "reinject.tmp"));
+                add_conv_op(c_t, whole(T), x1, hg_ins);
+                TView x2 = whole(new_tensor(mh, mh, F, "hg_ins"));
+                add_conv_op(c_i, ll2, x2, x1);
+                hg_ins = x2;
+            }
+        }
+    }
+};
+
+void add_param(dr_handle* h, const std::string& name, std::initializer_list<int> dims, bool trainable, ParamKind kind,
+               int conv) {
+    ParamInfo p;
+    p.name = name; p.trainable = trainable; p.kind = kind; p.conv = conv;
+    p.ndim = (int)dims.size();
+    p.count = 1;
+    int i = 0;
+    for (int d : dims) { p.dims[i++] = d; p.count *= (size_t)d; }
+    h->params.push_back(p);
+}
+
+}  // namespace
+
+static void free_all(dr_handle* h) {
+    for (void* p : {(void*)h->flat_param, (void*)h->flat_grad, (void*)h->adam_m, (void*)h->adam_v, (void*)h->flat_state,
+                    (void*)h->shadow, (void*)h->wp, (void*)h->wpT, (void*)h->fold, (void*)h->stats, (void*)h->bnc,
+                    (void*)h->act_arena, (void*)h->grad_arena, (void*)h->scratch, (void*)h->tiny, (void*)h->tiny_ext,
+                    (void*)h->losses})
+        if (p) rt::dfree(p);
+}
+
+// ==============================================================================================
+// C ABI
+// ==============================================================================================
+extern "C" {
+
+int dr_abi_version(void) { return DR_ABI_VERSION; }
+const char* dr_backend(void) { return rt::backend_name(); }
+
+const char* dr_last_error(const dr_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int dr_create(const dr_config* cfg, dr_handle** out) {
+    if (!cfg || !out) { g_create_err = "dr_create: null argument"; return DR_E_INVALID; }
+    *out = nullptr;
+    if (cfg->in_hw != 128 && cfg->in_hw != 256 && cfg->in_hw != 512) {
+        g_create_err = "unknown input depth map shape (um_v1.py:106-107): in_hw must be 128, 256 or 512";
+        return DR_E_UNSUPPORTED;
+    }
+    if (cfg->num_stack < 1 || cfg->num_fea < 8 || cfg->num_fea % 8 || cfg->num_jnt < 1 || cfg->max_batch < 1 ||
+        cfg->kernel_size != 3) {
+        g_create_err = "dr_create: need num_stack>=1, num_fea%8==0, num_jnt>=1, max_batch>=1, kernel_size==3";
+        return DR_E_INVALID;
+    }
+    if (rt::device_count() <= cfg->device || rt::set_device(cfg->device)) {
+        g_create_err = "dr_create: no such HIP device (the product path needs a gfx950 GPU; there is no CPU fallback)";
+        return DR_E_DEVICE;
+    }
+    auto* h = new dr_handle();
+    h->cfg = *cfg;
+    Builder b{h};
+    b.detect_net();
+
+    // ---- parameter registry + flat layouts (TF creation order) -------------------------------
+    size_t nt = 0, ns = 0, nsh = 0, nwp = 0, nwpT = 0, nfold = 0, nstat = 0, nbnc = 0;
+    for (int i = 0; i < (int)h->convs.size(); ++i) {
+        ConvLayer& c = h->convs[i];
+        const int taps = c.k * c.k;
+        add_param(h, c.name + "/weights", {c.k, c.k, c.cin, c.cout}, true, PK_WEIGHT, i);
+        c.w_off = nt; nt += (size_t)taps * c.cin * c.cout;
+        if (c.bn) {
+            const std::string bp = c.name + "/BatchReNorm/";
+            add_param(h, bp + "beta", {c.cout}, true, PK_BETA, i);   c.beta_off = nt;  nt += c.cout;
+            add_param(h, bp + "gamma", {c.cout}, true, PK_GAMMA, i); c.gamma_off = nt; nt += c.cout;
+            add_param(h, bp + "moving_mean", {c.cout}, false, PK_MMEAN, i);    c.mm_off = ns; ns += c.cout;
+            add_param(h, bp + "moving_variance", {c.cout}, false, PK_MVAR, i); c.mv_off = ns; ns += c.cout;
+            add_param(h, bp + "r_max", {1}, false, PK_RMAX, i);
+            add_param(h, bp + "d_max", {1}, false, PK_DMAX, i);
+            add_param(h, bp + "curr_t", {1}, false, PK_CURRT, i);
+            c.shadow_off = nsh; nsh += 2 * (size_t)c.cout;
+            c.fold_off = nfold; nfold += 2 * (size_t)c.cout;
+            c.stat_off = nstat; nstat += 4 * (size_t)c.cout;
+            c.bnc_off = nbnc; nbnc += 4 * (size_t)c.cout;
+        } else {
+            add_param(h, c.name + "/biases", {c.cout}, true, PK_BIAS, i); c.bias_off = nt; nt += c.cout;
+        }
+        if (c.k != 7) {
+            c.Kp = dr_round_up(c.cin, 16);  c.Np = dr_round_up(c.cout, 32);
+            c.KpT = dr_round_up(c.cout, 16); c.NpT = dr_round_up(c.cin, 32);
+            c.wp_off = nwp;   nwp += (size_t)taps * c.Kp * c.Np;
+            c.wpT_off = nwpT; nwpT += (size_t)taps * c.KpT * c.NpT;
+        }
+    }
+    h->n_train = nt; h->n_state = ns; h->n_shadow = nsh; h->n_wp = nwp; h->n_wpT = nwpT; h->n_fold = nfold;
+    h->n_stats = nstat; h->n_bnc = nbnc;
+
+    // ---- allocation ------------------------------------------------------------------------------
+    const size_t MB = (size_t)cfg->max_batch;
+    size_t nact = 0, max_t = 0;
+    for (auto& t : h->tensors) {
+        if (t.get() == h->input) continue;
+        const size_t n = MB * t->H * t->W * t->cs;
+        nact += n;
+        max_t = std::max(max_t, n);
+    }
+    size_t nraw = 0;
+    if (cfg->training)
+        for (auto& c : h->convs)
+            if (c.bn) nraw += MB * c.H * c.W * dr_round_up(c.cout, 4);
+    h->n_act = nact + nraw;
+    h->n_scratch = max_t;
+    bool ok = true;
+    auto alloc_f = [&](float*& p, size_t n) { p = (float*)rt::dmalloc(std::max<size_t>(n, 1) * sizeof(float)); ok = ok && p; };
+    alloc_f(h->flat_param, nt);
+    alloc_f(h->flat_state, ns);
+    alloc_f(h->wp, nwp);
+    alloc_f(h->fold, nfold);
+    alloc_f(h->act_arena, h->n_act);
+    alloc_f(h->scratch, h->n_scratch);
+    alloc_f(h->tiny, MB * h->map_hw * h->map_hw);
+    alloc_f(h->tiny_ext, MB * h->map_hw * h->map_hw);
+    alloc_f(h->losses, 4);
+    if (cfg->training) {
+        alloc_f(h->flat_grad, nt);
+        alloc_f(h->adam_m, nt);
+        alloc_f(h->adam_v, nt);
+        alloc_f(h->shadow, nsh);
+        alloc_f(h->wpT, nwpT);
+        alloc_f(h->bnc, nbnc);
+        h->stats = (double*)rt::dmalloc(std::max<size_t>(nstat, 1) * sizeof(double));
+        ok = ok && h->stats;
+        h->n_gact = nact;
+        alloc_f(h->grad_arena, nact);
+    }
+    if (!ok) {
+        free_all(h);
+        delete h;
+        g_create_err = "dr_create: device allocation failed";
+        return DR_E_NOMEM;
+    }
+    size_t off = 0;
+    for (auto& t : h->tensors) {
+        if (t.get() == h->input) continue;
+        t->p = h->act_arena + off;
+        if (cfg->training) t->g = h->grad_arena + off;
+        off += MB * t->H * t->W * t->cs;
+    }
+    if (cfg->training) {
+        for (auto& c : h->convs) {
+            if (!c.bn) continue;
+            auto t = std::make_unique<Tensor>();
+            t->id = (int)h->tensors.size();
+            t->H = c.H; t->W = c.W; t->C = c.cout; t->cs = dr_round_up(c.cout, 4); t->tag = "raw";
+            t->p = h->act_arena + off;
+            off += MB * t->H * t->W * t->cs;
+            c.raw = t.get();
+            h->tensors.push_back(std::move(t));
+        }
+    }
+    // pad channels are never written by the kernels: keep them (and everything else) finite
+    rt::memset_async(h->act_arena, 0, h->n_act * sizeof(float), nullptr);
+    rt::memset_async(h->flat_param, 0, nt * sizeof(float), nullptr);
+    rt::memset_async(h->flat_state, 0, std::max<size_t>(ns, 1) * sizeof(float), nullptr);
+    if (cfg->training) {
+        rt::memset_async(h->flat_grad, 0, nt * sizeof(float), nullptr);
+        rt::memset_async(h->adam_m, 0, nt * sizeof(float), nullptr);
+        rt::memset_async(h->adam_v, 0, nt * sizeof(float), nullptr);
+        rt::memset_async(h->shadow, 0, std::max<size_t>(nsh, 1) * sizeof(float), nullptr);
+        rt::memset_async(h->grad_arena, 0, nact * sizeof(float), nullptr);
+    }
+    rt::sync_stream(nullptr);
+    *out = h;
+    return DR_OK;
+}
+
+void dr_destroy(dr_handle* h) {
+    if (!h) return;
+    rt::sync_stream(nullptr);
+    free_all(h);
+    delete h;
+}
+
+int dr_param_count(const dr_handle* h) { return h ? (int)h->params.size() : 0; }
+
+int dr_param_info(const dr_handle* h, int index, const char** name, int32_t dims[4], int32_t* ndim, int32_t* trainable) {
+    if (!h) return DR_E_INVALID;
+    if (index < 0 || index >= (int)h->params.size()) DR_FAIL(h, DR_E_INVALID, "dr_param_info: index %d out of range", index);
+    const ParamInfo& p = h->params[index];
+    if (name) *name = p.name.c_str();
+    if (dims) for (int i = 0; i < 4; ++i) dims[i] = p.dims[i];
+    if (ndim) *ndim = p.ndim;
+    if (trainable) *trainable = p.trainable ? 1 : 0;
+    return DR_OK;
+}
+
+static const ParamInfo* find_param(const dr_handle* h, const char* name) {
+    for (auto& p : h->params)
+        if (p.name == name) return &p;
+    return nullptr;
+}
+
+static float* param_dev_ptr(dr_handle* h, const ParamInfo& p) {
+    ConvLayer& c = h->convs[p.conv];
+    switch (p.kind) {
+        case PK_WEIGHT: return h->flat_param + c.w_off;
+        case PK_BETA: return h->flat_param + c.beta_off;
+        case PK_GAMMA: return h->flat_param + c.gamma_off;
+        case PK_BIAS: return h->flat_param + c.bias_off;
+        case PK_MMEAN: return h->flat_state + c.mm_off;
+        case PK_MVAR: return h->flat_state + c.mv_off;
+        default: return nullptr;
+    }
+}
+
+int dr_load_param(dr_handle* h, const char* name, const float* host, size_t count) {
+    if (!h || !name || !host) return DR_E_INVALID;
+    const ParamInfo* p = find_param(h, name);
+    if (!p) DR_FAIL(h, DR_E_INVALID, "dr_load_param: unknown variable '%s'", name);
+    if (count != p->count) DR_FAIL(h, DR_E_INVALID, "dr_load_param: '%s' has %zu elements, got %zu", name, p->count, count);
+    ConvLayer& c = h->convs[p->conv];
+    if (p->kind == PK_RMAX) { c.r_max = host[0]; return DR_OK; }
+    if (p->kind == PK_DMAX) { c.d_max = host[0]; return DR_OK; }
+    if (p->kind == PK_CURRT) { c.curr_t = host[0]; return DR_OK; }
+    if (rt::h2d(param_dev_ptr(h, *p), host, count * sizeof(float), nullptr)) DR_FAIL(h, DR_E_DEVICE, "h2d failed");
+    rt::sync_stream(nullptr);
+    if (h->cfg.training && (p->kind == PK_MMEAN || p->kind == PK_MVAR)) c.shadow_step = 0;
+    h->finalized = false;
+    return DR_OK;
+}
+
+int dr_read_param(dr_handle* h, const char* name, float* host, size_t count) {
+    if (!h || !name || !host) return DR_E_INVALID;
+    const ParamInfo* p = find_param(h, name);
+    if (!p) DR_FAIL(h, DR_E_INVALID, "dr_read_param: unknown variable '%s'", name);
+    if (count != p->count) DR_FAIL(h, DR_E_INVALID, "dr_read_param: '%s' has %zu elements, got %zu", name, p->count, count);
+    ConvLayer& c = h->convs[p->conv];
+    if (p->kind == PK_RMAX) { host[0] = c.r_max; return DR_OK; }
+    if (p->kind == PK_DMAX) { host[0] = c.d_max; return DR_OK; }
+    if (p->kind == PK_CURRT) { host[0] = c.curr_t; return DR_OK; }
+    rt::sync_stream(nullptr);
+    if (rt::d2h(host, param_dev_ptr(h, *p), count * sizeof(float), nullptr)) DR_FAIL(h, DR_E_DEVICE, "d2h failed");
+    rt::sync_stream(nullptr);
+    return DR_OK;
+}
+
+static int repack_weights(dr_handle* h, hipStream_t s) {
+    for (auto& c : h->convs) {
+        if (c.k == 7) continue;
+        const int taps = c.k * c.k;
+        DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * c.Kp * c.Np)), dim3(256), 0, s,
+                  (const float*)(h->flat_param + c.w_off), h->wp + c.wp_off, taps, c.cin, c.cout, c.Kp, c.Np);
+        if (h->cfg.training)
+            DR_LAUNCH(pack_weights_T_kernel, dim3(grid_for((long)taps * c.KpT * c.NpT)), dim3(256), 0, s,
+                      (const float*)(h->flat_param + c.w_off), h->wpT + c.wpT_off, taps, c.cin, c.cout, c.KpT, c.NpT);
+    }
+    DR_CHECK_LAUNCH(h);
+    return DR_OK;
+}
+
+static int fold_bn(dr_handle* h, hipStream_t s) {
+    for (auto& c : h->convs) {
+        if (!c.bn) continue;
+        DR_LAUNCH(bn_fold_kernel, dim3(dr_ceil_div(c.cout, 256)), dim3(256), 0, s, (const float*)(h->flat_param + c.beta_off),
+                  (const float*)(h->flat_param + c.gamma_off), (const float*)(h->flat_state + c.mm_off),
+                  (const float*)(h->flat_state + c.mv_off), h->fold + c.fold_off, h->fold + c.fold_off + c.cout, c.cout,
+                  0.001f);
+    }
+    DR_CHECK_LAUNCH(h);
+    return DR_OK;
+}
+
+int dr_finalize_params(dr_handle* h, dr_stream stream) {
+    if (!h) return DR_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = repack_weights(h, s);
+    if (rc) return rc;
+    rc = fold_bn(h, s);
+    if (rc) return rc;
+    if (rt::sync_stream(s)) DR_FAIL(h, DR_E_DEVICE, "dr_finalize_params: stream sync failed");
+    DR_CHECK_LAUNCH(h);
+    h->finalized = true;
+    return DR_OK;
+}
+
+int dr_norm_dm(dr_handle* h, int B, const float* dm, const float* com, float* out, dr_stream stream) {
+    if (!h || !dm || !com || !out) return DR_E_INVALID;
+    if (B < 1) DR_FAIL(h, DR_E_INVALID, "dr_norm_dm: B=%d", B);
+    const int npix = h->cfg.in_hw * h->cfg.in_hw;
+    DR_LAUNCH(norm_dm_kernel, dim3(grid_for((long)B * npix)), dim3(256), 0, (hipStream_t)stream, dm, com, out, B, npix);
+    DR_CHECK_LAUNCH(h);
+    return DR_OK;
+}
+
+}  // extern "C"
+
+// ==============================================================================================
+// forward executor
+// ==============================================================================================
+static int run_conv_eval(dr_handle* h, const Op& op, int B, hipStream_t s) {
+    const ConvLayer& c = h->convs[op.conv];
+    if (op.kind == OP_STEM) {
+        StemParams sp{};
+        sp.x = h->dm_in; sp.B = B; sp.H = h->cfg.in_hw; sp.W = h->cfg.in_hw;
+        sp.w = h->flat_param + c.w_off;
+        sp.k = c.k; sp.stride = c.stride;
+        const int total = std::max((c.H - 1) * c.stride + c.k - sp.H, 0);
+        sp.pad_t = total / 2; sp.pad_l = total / 2;
+        sp.Ho = c.H; sp.Wo = c.W;
+        sp.y = op.out.t->p; sp.y_cs = op.out.t->cs;
+        sp.scale = h->fold + c.fold_off; sp.shift = h->fold + c.fold_off + c.cout; sp.relu = c.relu;
+        ProfScope ps(h, s, KID_STEM, 2.0 * B * c.H * c.W * c.k * c.k * c.cout,
+                     4.0 * B * (sp.H * sp.W + (double)c.H * c.W * c.cout));
+        DR_LAUNCH(stem_conv_kernel, dim3(dr_ceil_div(B * c.H * c.W, 64)), dim3(256), 0, s, sp);
+        return DR_OK;
+    }
+    ConvParams p{};
+    p.x = op.in.t->p; p.x_cs = op.in.t->cs; p.x_coff = op.in.coff; p.Cin = op.in.C;
+    p.B = B; p.H = c.H; p.W = c.W; p.ksize = c.k;
+    p.w = h->wp + c.wp_off; p.Kp = c.Kp; p.Np = c.Np;
+    p.y = op.out.t->p; p.y_cs = op.out.t->cs; p.y_coff = op.out.coff; p.Cout = c.cout;
+    if (c.bn) { p.scale = h->fold + c.fold_off; p.shift = h->fold + c.fold_off + c.cout; }
+    else { p.scale = nullptr; p.shift = h->flat_param + c.bias_off; }
+    p.relu = c.relu;
+    if (op.in2.valid()) { p.res = op.in2.t->p; p.res_cs = op.in2.t->cs; p.res_coff = op.in2.coff; }
+    if (op.masked) { p.rowmask = h->tiny; p.mask_thresh = -0.9f; }
+    ProfScope ps(h, s, conv_tile_id(p), 2.0 * B * c.H * c.W * c.k * c.k * c.cin * c.cout,
+                 4.0 * B * c.H * c.W * ((double)c.cin + c.cout + (op.in2.valid() ? c.cout : 0)));
+    if (launch_conv_igemm(p, s)) DR_FAIL(h, DR_E_STATE, "conv %s: unsupported layout", c.name.c_str());
+    return DR_OK;
+}
+
+static int run_simple_op(dr_handle* h, const Op& op, int B, hipStream_t s) {
+    const int kid = op.kind == OP_POOL ? KID_POOL : op.kind == OP_UPADD ? KID_UPADD : op.kind == OP_UVD ? KID_UVD : KID_COPY;
+    double bytes = 0;
+    if (op.kind == OP_POOL) bytes = 4.0 * B * op.in.C * ((double)op.in.t->H * op.in.t->W + (double)op.out.t->H * op.out.t->W);
+    if (op.kind == OP_UPADD) bytes = 4.0 * B * op.out.C * (2.25 * op.out.t->H * op.out.t->W);
+    if (op.kind == OP_COPY) bytes = 8.0 * B * op.in.C * op.in.t->H * op.in.t->W;
+    ProfScope ps(h, s, kid, 0.0, bytes);
+    switch (op.kind) {
+        case OP_POOL: {
+            const Tensor* ti = op.in.t; const Tensor* to = op.out.t;
+            const int k = op.pool_k;
+            const int total = std::max((to->H - 1) * 2 + k - ti->H, 0);
+            DR_LAUNCH(maxpool_kernel, dim3(grid_for((long)B * to->H * to->W * (op.in.C / 4))), dim3(256), 0, s,
+                      (const float*)ti->p, ti->cs, op.in.coff, B, ti->H, ti->W, op.in.C, k, total / 2, total / 2, to->p,
+                      to->cs, op.out.coff, to->H, to->W);
+            break;
+        }
+        case OP_UPADD: {
+            const Tensor* to = op.out.t;
+            DR_LAUNCH(upsample_add_kernel, dim3(grid_for((long)B * to->H * to->W * (op.out.C / 4))), dim3(256), 0, s,
+                      (const float*)op.in.t->p, op.in.t->cs, op.in.coff, (const float*)op.in2.t->p, op.in2.t->cs,
+                      op.in2.coff, to->p, to->cs, op.out.coff, B, to->H, to->W, op.out.C);
+            break;
+        }
+        case OP_UVD: {
+            const int mh = h->map_hw;
+            DR_LAUNCH(uvd_kernel, dim3(grid_for((long)B * mh * mh)), dim3(256), 0, s, h->dm_in, B, h->cfg.in_hw, h->tiny,
+                      op.uvd0.t->p, op.uvd0.t->cs, op.uvd0.coff, op.uvd1.t->p, op.uvd1.t->cs, op.uvd1.coff);
+            break;
+        }
+        case OP_COPY: {
+            const long M = (long)B * op.in.t->H * op.in.t->W;
+            DR_LAUNCH(copy_channels_kernel, dim3(grid_for(M * op.in.C)), dim3(256), 0, s, (const float*)op.in.t->p,
+                      op.in.t->cs, op.in.coff, op.out.t->p, op.out.t->cs, op.out.coff, M, op.in.C, 0);
+            break;
+        }
+        default: break;
+    }
+    return DR_OK;
+}
+
+static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s) {
+    if (!h->finalized) DR_FAIL(h, DR_E_STATE, "forward before dr_finalize_params");
+    if (B < 1 || B > h->cfg.max_batch) DR_FAIL(h, DR_E_INVALID, "batch %d outside [1, max_batch=%d]", B, h->cfg.max_batch);
+    h->dm_in = dm;
+    for (const Op& op : h->ops) {
+        int rc = (op.kind == OP_CONV || op.kind == OP_STEM) ? run_conv_eval(h, op, B, s) : run_simple_op(h, op, B, s);
+        if (rc) return rc;
+    }
+    DR_CHECK_LAUNCH(h);
+    h->last_forward_train = false;
+    h->last_B = B;
+    return DR_OK;
+}
+
+static void copy_out(dr_handle* h, const Tensor* t, int B, float* dst, hipStream_t s) {
+    const long M = (long)B * t->H * t->W;
+    DR_LAUNCH(copy_channels_kernel, dim3(grid_for(M * t->C)), dim3(256), 0, s, (const float*)t->p, t->cs, 0, dst, t->C, 0, M,
+              t->C, 0);
+}
+
+static int vote_impl(dr_handle* h, int B, View hm, View hm3, View um, const float* tiny, const float* cfg, const float* com,
+                     float* xyz, hipStream_t s) {
+    VoteParams vp{};
+    vp.hm = hm; vp.hm3 = hm3; vp.um = um; vp.tiny = tiny; vp.cfg = cfg; vp.com = com; vp.xyz_mm = xyz; vp.xyz_norm = nullptr;
+    vp.B = B; vp.h = h->map_hw; vp.w = h->map_hw; vp.J = h->cfg.num_jnt;
+    const int npix = vp.h * vp.w;
+    if (npix > kVoteMaxPix) DR_FAIL(h, DR_E_UNSUPPORTED, "vote: map of %d px exceeds the LDS plan", npix);
+    {
+        ProfScope ps(h, s, KID_VOTE, 0.0, (double)B * ((5.0 * vp.J + 1.0) * npix * 4.0 + 12.0 * vp.J));
+        DR_LAUNCH(vote_kernel, dim3(B, dr_ceil_div(vp.J, kVoteJC)), dim3(256), (size_t)kVoteJC * npix * sizeof(float), s, vp);
+    }
+    DR_CHECK_LAUNCH(h);
+    return DR_OK;
+}
+
+extern "C" {
+
+int dr_forward_eval(dr_handle* h, int B, const float* dm, float* hm, float* hm3, float* um, dr_stream stream) {
+    if (!h || !dm) return DR_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = forward_eval_impl(h, B, dm, s);
+    if (rc) return rc;
+    return dr_read_maps(h, B, h->cfg.num_stack - 1, hm, hm3, um, stream);
+}
+
+int dr_read_maps(dr_handle* h, int B, int stack, float* hm, float* hm3, float* um, dr_stream stream) {
+    if (!h) return DR_E_INVALID;
+    if (stack < 0 || stack >= h->cfg.num_stack) DR_FAIL(h, DR_E_INVALID, "dr_read_maps: stack %d", stack);
+    if (B < 1 || B > h->last_B) DR_FAIL(h, DR_E_INVALID, "dr_read_maps: B=%d but the last forward ran %d", B, h->last_B);
+    hipStream_t s = (hipStream_t)stream;
+    if (hm) copy_out(h, h->hm[stack], B, hm, s);
+    if (hm3) copy_out(h, h->hm3[stack], B, hm3, s);
+    if (um) copy_out(h, h->um[stack], B, um, s);
+    DR_CHECK_LAUNCH(h);
+    return DR_OK;
+}
+
+int dr_vote(dr_handle* h, int B, const float* hm, const float* hm3, const float* um, const float* dm, const float* cfg,
+            const float* com, float* xyz, dr_stream stream) {
+    if (!h || !hm || !hm3 || !um || !dm || !cfg || !com || !xyz) return DR_E_INVALID;
+    if (B < 1 || B > h->cfg.max_batch) DR_FAIL(h, DR_E_INVALID, "batch %d outside [1, max_batch=%d]", B, h->cfg.max_batch);
+    hipStream_t s = (hipStream_t)stream;
+    const int J = h->cfg.num_jnt, mh = h->map_hw;
+    DR_LAUNCH(uvd_kernel, dim3(grid_for((long)B * mh * mh)), dim3(256), 0, s, dm, B, h->cfg.in_hw, h->tiny_ext, (float*)nullptr,
+              0, 0, (float*)nullptr, 0, 0);
+    return vote_impl(h, B, View{(float*)hm, J, 0, J}, View{(float*)hm3, J, 0, J}, View{(float*)um, 3 * J, 0, 3 * J},
+                     h->tiny_ext, cfg, com, xyz, s);
+}
+
+int dr_infer(dr_handle* h, int B, const float* dm, const float* cfg, const float* com, float* xyz, dr_stream stream) {
+    if (!h || !dm || !cfg || !com || !xyz) return DR_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = forward_eval_impl(h, B, dm, s);
+    if (rc) return rc;
+    const int S = h->cfg.num_stack - 1;
+    TView a{h->hm[S], 0, h->hm[S]->C}, b{h->hm3[S], 0, h->hm3[S]->C}, c{h->um[S], 0, h->um[S]->C};
+    return vote_impl(h, B, a.fwd(), b.fwd(), c.fwd(), h->tiny, cfg, com, xyz, s);
+}
+
+int dr_read_activation(dr_handle* h, const char* scope, int B, float* host, size_t count) {
+    if (!h || !scope || !host) return DR_E_INVALID;
+    for (const Op& op : h->ops) {
+        if ((op.kind != OP_CONV && op.kind != OP_STEM) || h->convs[op.conv].name != scope) continue;
+        const Tensor* t = op.out.t;
+        const long M = (long)B * t->H * t->W;
+        const size_t need = (size_t)M * op.out.C;
+        if (count != need) DR_FAIL(h, DR_E_INVALID, "dr_read_activation: %s has %zu elements, got %zu", scope, need, count);
+        if (need > h->n_scratch) DR_FAIL(h, DR_E_STATE, "scratch too small");
+        DR_LAUNCH(copy_channels_kernel, dim3(grid_for(M * op.out.C)), dim3(256), 0, (hipStream_t) nullptr, (const float*)t->p,
+                  t->cs, op.out.coff, h->scratch, op.out.C, 0, M, op.out.C, 0);
+        rt::sync_stream(nullptr);
+        rt::d2h(host, h->scratch, need * sizeof(float), nullptr);
+        rt::sync_stream(nullptr);
+        DR_CHECK_LAUNCH(h);
+        return DR_OK;
+    }
+    DR_FAIL(h, DR_E_INVALID, "dr_read_activation: unknown conv scope '%s'", scope);
+}
+
+double dr_conv_flops_per_crop(const dr_handle* h) { return h ? h->flops_per_crop : 0.0; }
+
+}  // extern "C"
+
+#include "train_exec.inc"
+
+// ==============================================================================================
+// test hooks (include/densereg_debug.h)
+// ==============================================================================================
+#include "../../include/densereg_debug.h"
+extern "C" int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, const float* x, int x_cs, const float* w,
+                             const float* scale, const float* shift, int relu, const float* res, int res_cs,
+                             const float* rowmask, float thresh, float* y, int y_cs, double* stat, dr_stream stream) {
+    if (!x || !w || !y || (k != 1 && k != 3)) return DR_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int taps = k * k, Kp = dr_round_up(Cin, 16), Np = dr_round_up(Cout, 32);
+    float* wp = (float*)rt::dmalloc((size_t)taps * Kp * Np * sizeof(float));
+    if (!wp) return DR_E_NOMEM;
+    DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, w, wp, taps, Cin, Cout, Kp, Np);
+    ConvParams p{};
+    p.x = x; p.x_cs = x_cs; p.x_coff = 0; p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.ksize = k;
+    p.w = wp; p.Kp = Kp; p.Np = Np; p.y = y; p.y_cs = y_cs; p.y_coff = 0; p.Cout = Cout;
+    p.scale = scale; p.shift = shift; p.relu = relu; p.res = res; p.res_cs = res_cs; p.res_coff = 0;
+    p.rowmask = rowmask; p.mask_thresh = thresh;
+    p.stat_sum = stat; p.stat_sq = stat ? stat + Cout : nullptr;
+    int rc = launch_conv_igemm(p, s);
+    rt::sync_stream(s);
+    rt::dfree(wp);
+    std::string m;
+    if (rc || rt::last_error(&m)) return DR_E_DEVICE;
+    return DR_OK;
+}
+
+extern "C" int dr_profile_enable(dr_handle* h, int on) {
+    if (!h) return DR_E_INVALID;
+    rt::sync_stream(nullptr);
+    for (auto& r : h->prof) { rt::event_destroy(r.a); rt::event_destroy(r.b); }
+    h->prof.clear();
+    h->profiling = on != 0;
+    return DR_OK;
+}
+
+extern "C" int dr_profile_read(dr_handle* h, dr_kernel_stat* out, int max_out, int* n_out) {
+    if (!h || !out || !n_out) return DR_E_INVALID;
+    rt::sync_stream(nullptr);
+    dr_kernel_stat agg[KID_COUNT];
+    memset(agg, 0, sizeof(agg));
+    for (int k = 0; k < KID_COUNT; ++k) snprintf(agg[k].name, sizeof(agg[k].name), "%s", kKernelNames[k]);
+    for (auto& r : h->prof) {
+        agg[r.kid].launches += 1;
+        agg[r.kid].total_ms += rt::event_elapsed_ms(r.a, r.b);
+        agg[r.kid].flops += r.flops;
+        agg[r.kid].bytes += r.bytes;
+        rt::event_destroy(r.a); rt::event_destroy(r.b);
+    }
+    h->prof.clear();
+    int n = 0;
+    for (int k = 0; k < KID_COUNT && n < max_out; ++k)
+        if (agg[k].launches) out[n++] = agg[k];
+    *n_out = n;
+    return DR_OK;
+}

@@ -1,0 +1,75 @@
+// dr_platform.h -- the one place that knows whether we compile for gfx950 (hipcc, the product)
+// or for the host-fiber emulator used by the CPU-side unit tests (tests/hipemu, -DDR_EMU).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#if defined(DR_EMU)
+// ---------------------------------------------------------------------------------------------
+// Test build: same kernel sources, executed by tests/hipemu/hip_emu.h.  Never shipped.
+// ---------------------------------------------------------------------------------------------
+#include "hip_emu.h"
+#define DR_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipemu_launch(kernel, grid, block, smem, stream, __VA_ARGS__)
+#define DR_DYN_SMEM(name) char* name = hipemu_dyn_smem()
+namespace dr { namespace rt {
+inline const char* backend_name() { return "hipemu"; }
+inline int set_device(int) { return 0; }
+inline int device_count() { return 1; }
+inline void* dmalloc(size_t n) { void* p = nullptr; if (posix_memalign(&p, 256, n ? n : 256)) return nullptr; return p; }
+inline void dfree(void* p) { free(p); }
+inline int memset_async(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+inline int h2d(void* d, const void* h, size_t n, hipStream_t) { memcpy(d, h, n); return 0; }
+inline int d2h(void* h, const void* d, size_t n, hipStream_t) { memcpy(h, d, n); return 0; }
+inline int d2d(void* d, const void* s, size_t n, hipStream_t) { memcpy(d, s, n); return 0; }
+inline int sync_stream(hipStream_t) { return 0; }
+inline int last_error(std::string*) { return 0; }
+struct Event { int dummy; };
+inline Event event_create() { return Event{0}; }
+inline void event_destroy(Event) {}
+inline void event_record(Event, hipStream_t) {}
+inline float event_elapsed_ms(Event, Event) { return 0.f; }
+}}  // namespace dr::rt
+#else
+// ---------------------------------------------------------------------------------------------
+// Product build: HIP for gfx950.
+// ---------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+#define DR_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__)
+#define DR_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+namespace dr { namespace rt {
+inline const char* backend_name() { return "hip-gfx950"; }
+inline int set_device(int d) { return hipSetDevice(d) == hipSuccess ? 0 : -1; }
+inline int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+inline void* dmalloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n ? n : 256) != hipSuccess) return nullptr; return p; }
+inline void dfree(void* p) { (void)hipFree(p); }
+inline int memset_async(void* p, int v, size_t n, hipStream_t s) { return hipMemsetAsync(p, v, n, s) == hipSuccess ? 0 : -1; }
+inline int h2d(void* d, const void* h, size_t n, hipStream_t s) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1; }
+inline int d2h(void* h, const void* d, size_t n, hipStream_t s) { return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess ? 0 : -1; }
+inline int d2d(void* d, const void* s_, size_t n, hipStream_t s) { return hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1; }
+inline int sync_stream(hipStream_t s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+inline int last_error(std::string* msg) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    if (msg) *msg = hipGetErrorString(e);
+    return -1;
+}
+struct Event { hipEvent_t e; };
+inline Event event_create() { Event ev{}; (void)hipEventCreate(&ev.e); return ev; }
+inline void event_destroy(Event ev) { (void)hipEventDestroy(ev.e); }
+inline void event_record(Event ev, hipStream_t s) { (void)hipEventRecord(ev.e, s); }
+inline float event_elapsed_ms(Event a, Event b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, a.e, b.e); return ms; }
+}}  // namespace dr::rt
+#endif
+
+typedef float dr_f32x16 __attribute__((ext_vector_type(16)));
+typedef float dr_f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int dr_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int dr_round_up(int a, int b) { return dr_ceil_div(a, b) * b; }

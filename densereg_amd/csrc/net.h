@@ -1,0 +1,129 @@
+// net.h -- the runtime around the kernels: graph builder for network/um_v1.py, parameter registry
+// (TF variable names), buffer plan, and the forward/backward executors.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/densereg.h"
+#include "dr_platform.h"
+#include "kernels_misc.h"
+
+namespace dr {
+
+struct Tensor {
+    int id = 0;
+    int H = 0, W = 0, C = 0, cs = 0;   // cs = channel stride (C rounded up to 4)
+    float* p = nullptr;                // forward values   [max_batch*H*W*cs]
+    float* g = nullptr;                // gradient buffer (training handles)
+    bool needs_grad = true;
+    std::string tag;
+};
+
+struct TView {
+    Tensor* t = nullptr;
+    int coff = 0;
+    int C = 0;
+    bool valid() const { return t != nullptr; }
+    View fwd() const { return View{t->p, t->cs, coff, C}; }
+    View grad() const { return View{t->g, t->cs, coff, C}; }
+};
+
+struct ConvLayer {
+    std::string name;                  // TF scope: 'hg_imgproc/Conv_3', 'Conv_40'
+    int k = 1, stride = 1, cin = 0, cout = 0;
+    bool bn = false, relu = false;
+    float wd = 0.f;
+    int H = 0, W = 0;                  // output spatial dims
+    // offsets (in floats) into the flat trainable buffer
+    size_t w_off = 0, beta_off = 0, gamma_off = 0, bias_off = 0;
+    // offsets into the flat state buffer (moving_mean, moving_variance)
+    size_t mm_off = 0, mv_off = 0;
+    float r_max = 1.f, d_max = 0.f, curr_t = 0.f;      // BatchReNorm schedule scalars (ops.py:114-128)
+    // zero-debias shadow of assign_moving_average [TF1.3-semantics]: biased accumulators + step
+    size_t shadow_off = 0;             // 2*cout floats in the shadow buffer (biased mean, biased var)
+    int shadow_step = 0;
+    // packed weights
+    int Kp = 0, Np = 0;                // forward:  [taps][Kp][Np]
+    int KpT = 0, NpT = 0;              // dgrad:    [taps][KpT][NpT]  (cout -> K, cin -> N, taps flipped)
+    size_t wp_off = 0, wpT_off = 0;    // offsets into the packed buffers
+    size_t fold_off = 0;               // 2*cout floats: scale, shift (eval fold or train step values)
+    size_t stat_off = 0;               // 4*cout doubles: sum, sumsq (fwd) ; sum g, sum g*yhat (bwd)
+    size_t bnc_off = 0;                // 4*cout floats: mean, inv_std, r, d saved by the train forward
+    Tensor* raw = nullptr;             // pre-BN conv output (training)
+};
+
+enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_UPADD, OP_UVD, OP_COPY };
+
+struct Op {
+    OpKind kind;
+    TView in, in2, out;                // in2: residual source (conv) / low-res input (upadd)
+    int conv = -1;                     // ConvLayer index
+    bool masked = false;               // depth mask on the input rows (um_v1.py:146-148)
+    int dropout = -1;                  // dropout slot index (stack*2 + i) or -1
+    int pool_k = 0;
+    TView uvd0, uvd1;                  // OP_UVD destinations
+};
+
+enum ParamKind { PK_WEIGHT, PK_BETA, PK_GAMMA, PK_BIAS, PK_MMEAN, PK_MVAR, PK_RMAX, PK_DMAX, PK_CURRT };
+
+struct ParamInfo {
+    std::string name;
+    int32_t dims[4] = {0, 0, 0, 0};
+    int32_t ndim = 0;
+    bool trainable = false;
+    ParamKind kind = PK_WEIGHT;
+    int conv = -1;
+    size_t count = 0;
+};
+
+enum KernelId {
+    KID_CONV_128x128, KID_CONV_128x64, KID_CONV_64x64, KID_CONV_128x32, KID_STEM, KID_POOL, KID_UPADD, KID_UVD, KID_COPY,
+    KID_VOTE, KID_BN, KID_WGRAD, KID_ELTWISE, KID_LOSS, KID_ADAM, KID_COUNT
+};
+static const char* const kKernelNames[KID_COUNT] = {
+    "conv_igemm_128x128", "conv_igemm_128x64", "conv_igemm_64x64", "conv_igemm_128x32", "stem_conv", "maxpool",
+    "upsample_add", "uvd", "copy_channels", "vote", "batch_renorm", "conv_wgrad", "eltwise_bwd", "loss", "adam"};
+
+struct ProfRecord { rt::Event a, b; int kid; double flops; double bytes; };
+
+}  // namespace dr
+
+struct dr_handle {
+    dr_config cfg{};
+    mutable std::string err;
+    std::vector<std::unique_ptr<dr::Tensor>> tensors;
+    std::vector<dr::ConvLayer> convs;
+    std::vector<dr::Op> ops;
+    std::vector<dr::ParamInfo> params;
+    int map_hw = 0;
+
+    // device buffers
+    float* flat_param = nullptr; size_t n_train = 0;
+    float* flat_grad = nullptr;  float* adam_m = nullptr; float* adam_v = nullptr;
+    float* flat_state = nullptr; size_t n_state = 0;       // moving stats
+    float* shadow = nullptr;     size_t n_shadow = 0;      // zero-debias biased accumulators
+    float* wp = nullptr;         size_t n_wp = 0;          // packed forward weights
+    float* wpT = nullptr;        size_t n_wpT = 0;         // packed dgrad weights
+    float* fold = nullptr;       size_t n_fold = 0;        // per-BN-layer scale|shift
+    double* stats = nullptr;     size_t n_stats = 0;
+    float* bnc = nullptr;        size_t n_bnc = 0;
+    float* act_arena = nullptr;  size_t n_act = 0;
+    float* grad_arena = nullptr; size_t n_gact = 0;
+    float* scratch = nullptr;    size_t n_scratch = 0;     // dRaw scratch (training) / dense copies
+    float* tiny = nullptr;                                  // (B,h,w) normalised depth at map resolution
+    float* tiny_ext = nullptr;                              // same, for dr_vote on external maps
+    float* losses = nullptr;                                // 4 floats (device)
+    const float* dm_in = nullptr;                           // input of the last forward (not owned)
+
+    // network outputs per stack (dense-ish tensors)
+    std::vector<dr::Tensor*> hm, hm3, um;
+    dr::Tensor* input = nullptr;       // not allocated: points at caller's dm
+    bool finalized = false;
+    bool last_forward_train = false;
+    int last_B = 0;
+    int dropout_mode = 0; const uint8_t* keep_mask = nullptr; uint64_t seed = 0;
+    double flops_per_crop = 0.0;
+    bool profiling = false;
+    std::vector<dr::ProfRecord> prof;
+};

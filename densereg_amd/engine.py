@@ -1,0 +1,143 @@
+"""Torch-facing engine: device memory and streams come from PyTorch-ROCm, all compute from the HIP
+library behind the C ABI (``include/densereg.h``).  There is no eager / CPU fallback here: every
+method hands raw device pointers to ``libdensereg_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), 'engine tensors must be contiguous device tensors'
+    return t.data_ptr()
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    assert t.dtype == torch.float32
+    return t
+
+
+class Engine:
+    """One engine per (process, device).  Mirrors the call sites of the reference:
+
+    * ``forward_eval`` / ``forward_train``  <->  ``um_v1.detect_net(dm, cfgs, coms, J, is_training)``
+    * ``vote`` / ``infer``                  <->  ``JointDetectionModel._xyz_estimation`` / ``.test``
+    * ``loss`` / ``backward`` / ``apply_adam`` <-> ``.loss`` and the step of ``train_single_gpu.train``
+    """
+
+    def __init__(self, num_stack=2, num_fea=128, num_jnt=16, in_hw=128, kernel_size=3, max_batch=40,
+                 device: int = 0, training: bool = False):
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', device)
+        with torch.cuda.device(self.device):
+            self.h = _lib.Handle(self.lib, num_stack, num_fea, num_jnt, in_hw, kernel_size, max_batch, device, training)
+        self.num_stack, self.num_fea, self.num_jnt, self.in_hw = num_stack, num_fea, num_jnt, in_hw
+        self.map_hw = in_hw // 4
+        self.max_batch = max_batch
+        self.training = training
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        self.h.close()
+
+    def load_params(self, params: Dict[str, np.ndarray]):
+        self.h.load_params(params)
+        self.h.call('dr_finalize_params', self._stream())
+
+    def read_params(self) -> Dict[str, np.ndarray]:
+        torch.cuda.synchronize(self.device)
+        return self.h.read_params()
+
+    def param_infos(self):
+        return self.h.param_infos()
+
+    def new(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    # ---- the path ---------------------------------------------------------------------------
+    def norm_dm(self, dm_mm: torch.Tensor, com: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(dm_mm)
+        self.h.call('dr_norm_dm', dm_mm.shape[0], _p(_f32(dm_mm)), _p(_f32(com)), _p(out), self._stream())
+        return out
+
+    def forward_eval(self, dm_norm: torch.Tensor, want_maps: bool = True):
+        B, J, m = dm_norm.shape[0], self.num_jnt, self.map_hw
+        hm = hm3 = um = None
+        if want_maps:
+            hm, hm3, um = self.new(B, m, m, J), self.new(B, m, m, J), self.new(B, m, m, 3 * J)
+        self.h.call('dr_forward_eval', B, _p(_f32(dm_norm)), _p(hm), _p(hm3), _p(um), self._stream())
+        return hm, hm3, um
+
+    def read_maps(self, B: int, stack: int):
+        J, m = self.num_jnt, self.map_hw
+        hm, hm3, um = self.new(B, m, m, J), self.new(B, m, m, J), self.new(B, m, m, 3 * J)
+        self.h.call('dr_read_maps', B, stack, _p(hm), _p(hm3), _p(um), self._stream())
+        return hm, hm3, um
+
+    def vote(self, hm, hm3, um, dm_norm, cfg, com) -> torch.Tensor:
+        B = dm_norm.shape[0]
+        xyz = self.new(B, 3 * self.num_jnt)
+        self.h.call('dr_vote', B, _p(hm), _p(hm3), _p(um), _p(dm_norm), _p(cfg), _p(com), _p(xyz), self._stream())
+        return xyz
+
+    def infer(self, dm_norm, cfg, com, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B = dm_norm.shape[0]
+        xyz = out if out is not None else self.new(B, 3 * self.num_jnt)
+        self.h.call('dr_infer', B, _p(dm_norm), _p(cfg), _p(com), _p(xyz), self._stream())
+        return xyz
+
+    def read_activation(self, scope: str, B: int, shape) -> np.ndarray:
+        torch.cuda.synchronize(self.device)
+        a = np.empty(shape, np.float32)
+        self.h.call('dr_read_activation', scope.encode(), B, a.ctypes.data, a.size)
+        return a
+
+    # ---- training ---------------------------------------------------------------------------
+    def forward_train(self, dm_norm, dropout_mode=_lib.DROPOUT_RNG, keep_mask: Optional[torch.Tensor] = None, seed: int = 0):
+        self.h.call('dr_forward_train', dm_norm.shape[0], _p(_f32(dm_norm)), int(dropout_mode), _p(keep_mask),
+                    C.c_uint64(seed), self._stream())
+
+    def loss(self, dm_norm, pose_mm, cfg, com) -> torch.Tensor:
+        out = self.new(4)
+        self.h.call('dr_loss', dm_norm.shape[0], _p(dm_norm), _p(_f32(pose_mm)), _p(_f32(cfg)), _p(_f32(com)), _p(out),
+                    self._stream())
+        return out
+
+    def backward(self, B: int):
+        self.h.call('dr_backward', B, self._stream())
+
+    def zero_grad(self):
+        self.h.call('dr_zero_grad', self._stream())
+
+    def apply_adam(self, lr: float, div: float, step: int, clip: float = 0.2):
+        self.h.call('dr_apply_adam', C.c_float(lr), C.c_float(div), C.c_float(clip), C.c_int64(step), self._stream())
+
+    def flat_view(self, which: str) -> torch.Tensor:
+        """Zero-copy torch view of the flat fp32 gradient / parameter buffer (for RCCL all-reduce)."""
+        ptr, n = self.h.flat(which)
+        return _as_tensor(ptr, n, self.device)
+
+    def conv_flops_per_crop(self) -> float:
+        return self.h.conv_flops_per_crop()
+
+
+class _CudaArray:
+    """``__cuda_array_interface__`` shim so torch can alias library-owned device memory."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
+
+
+def _as_tensor(ptr: int, n: int, device) -> torch.Tensor:
+    return torch.as_tensor(_CudaArray(ptr, n), device=device)

@@ -1,0 +1,72 @@
+"""Data-parallel training step: one process per GPU, one RCCL all-reduce per optimizer step.
+
+Semantics: the reference's working trainer accumulates gradients over
+``sub_batch`` micro-batches, divides, clips to +-0.2 and applies Adam
+(``model/train_single_gpu.py:69-89,144-150``); its multi-GPU sketch averages per-tower gradients
+(``model/train_multi_gpu.py:16-39``) with per-tower BatchReNorm statistics (:63-64, 85-86).  Here every
+rank owns a full replica, accumulates its local micro-batches into the engine's flat fp32 gradient
+buffer, and once per optimizer step the flat buffer is all-reduced (sum) over RCCL/xGMI; the division
+by ``sub_batch * world`` happens inside the fused clip+Adam kernel.  Crops are independent units, so
+there is no other data-path collective; moving BatchReNorm statistics stay per-rank.
+"""
+from __future__ import annotations
+
+import math
+
+from .data.synthetic import DATASETS
+
+INIT_LR = 0.001            # hourglass_um_crop_tiny.py:69
+LR_DECAY = 0.1             # :74
+GRAD_CLIP = 0.2            # train_single_gpu.py:86
+
+
+def decay_steps(dataset: str, batch_size: int, sub_batch: int) -> float:
+    """hourglass_um_crop_tiny.py:109,174: (approximate_num / (batch*sub_batch)) * epochs_per_decay (a float)."""
+    ds = DATASETS[dataset]
+    return ds['approximate_num'] / float(batch_size * sub_batch) * ds['epochs_per_decay']
+
+
+def learning_rate(step: int, dataset: str, batch_size: int, sub_batch: int) -> float:
+    """tf.train.exponential_decay(staircase=True) of train_single_gpu.py:45-49."""
+    return INIT_LR * LR_DECAY ** math.floor(step / decay_steps(dataset, batch_size, sub_batch))
+
+
+class DataParallelTrainer:
+    def __init__(self, engine, dataset: str = 'nyu', sub_batch: int = 5, dist=None, all_reduce=None):
+        self.eng = engine
+        self.dataset = dataset
+        self.sub_batch = int(sub_batch)
+        self.dist = dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self._all_reduce = all_reduce            # injectable (gloo tests)
+        self.micro = 0
+        self.global_step = 0                     # optimizer steps applied so far
+        self.flat_grad = engine.flat_view('grad') if engine is not None else None
+        if engine is not None:
+            engine.zero_grad()
+
+    def reduce_gradients(self):
+        if self.world > 1:
+            if self._all_reduce is not None:
+                self._all_reduce(self.flat_grad)
+            else:
+                self.dist.all_reduce(self.flat_grad, op=self.dist.ReduceOp.SUM)
+
+    def micro_step(self, dm_norm, pose_mm, cfg, com, seed: int = 0, dropout_mode: int = 2, keep_mask=None):
+        """One ``sess.run([accum_op, batchnorm_update_op, loss])`` (:146); returns the 4 loss terms (device)."""
+        eng = self.eng
+        eng.forward_train(dm_norm, dropout_mode, keep_mask, seed)
+        losses = eng.loss(dm_norm, pose_mm, cfg, com)
+        eng.backward(dm_norm.shape[0])
+        self.micro += 1
+        if self.micro % self.sub_batch == 0:
+            self.optimizer_step(dm_norm.shape[0])
+        return losses
+
+    def optimizer_step(self, batch_size: int):
+        """``sess.run(train_op)`` (:150) then ``reset_op`` (:144)."""
+        self.reduce_gradients()
+        lr = learning_rate(self.global_step, self.dataset, batch_size, self.sub_batch)
+        self.global_step += 1
+        self.eng.apply_adam(lr, float(self.sub_batch * self.world), self.global_step, GRAD_CLIP)
+        self.eng.zero_grad()

@@ -1,0 +1,132 @@
+/* densereg.h -- C ABI of libdensereg_hip.so: the MI355X (gfx950) dense-regression hand-pose engine.
+ *
+ * The reference (melonwan/denseReg) has no native interface: its hot path is a Python callable
+ * contract inside a TF-1.3 graph.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference tree):
+ *
+ *   network plug-in    network/um_v1.py:71        detect_net(dm, cfgs, coms, num_jnt, is_training)
+ *                      loaded through importlib at model/hourglass_um_crop_tiny.py:863-867
+ *   vote               model/hourglass_um_crop_tiny.py:743   _xyz_estimation(...) preceded by
+ *                      _resume_om (:457) and followed by unnorm_xyz_pose (:462)
+ *   loss               model/hourglass_um_crop_tiny.py:323   JointDetectionModel.loss
+ *   optimizer          model/train_single_gpu.py:71-89,144-150  accumulate / clip / Adam apply
+ *   variables          network/slim/variables.py:247  (names: <scope>/Conv_k/weights, .../BatchReNorm/...)
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative DR_E_* code otherwise; dr_last_error() gives
+ *     the message (per handle; pass NULL for errors of dr_create).
+ *   - one handle per (process, device); calls on one handle are NOT re-entrant.
+ *   - all *_dev pointers are device (HBM) pointers owned by the caller; tensors are dense NHWC
+ *     float32 exactly as the reference feeds/fetches them.  All work is enqueued on `stream`
+ *     (a hipStream_t; NULL = the null stream); nothing synchronises unless stated.
+ *   - the library owns weights, workspaces, saved activations, gradient and Adam buffers.
+ */
+#ifndef DENSEREG_H_
+#define DENSEREG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DR_ABI_VERSION 1
+
+enum {
+    DR_OK = 0,
+    DR_E_INVALID = -1,      /* bad argument (null pointer, batch > max_batch, unknown name ...) */
+    DR_E_UNSUPPORTED = -2,  /* in_hw not in {128,256,512}: um_v1.py:106-107 raises ValueError */
+    DR_E_STATE = -3,        /* call order (params not finalised, handle not created for training) */
+    DR_E_DEVICE = -4,       /* HIP runtime error */
+    DR_E_NOMEM = -5
+};
+
+typedef struct dr_handle dr_handle;
+typedef void* dr_stream;    /* hipStream_t */
+
+/* Flags the reference reads as process globals (hourglass_um_crop_tiny.py:29-60) + sizing. */
+typedef struct dr_config {
+    int32_t num_stack;      /* --num_stack   (default 2)   */
+    int32_t num_fea;        /* --num_fea / --fea_num (128) */
+    int32_t num_jnt;        /* dataset.jnt_num: icvl 16, nyu 14, msra 21 */
+    int32_t in_hw;          /* input crop side, 128 (256/512 accepted by um_v1.py:99-104) */
+    int32_t kernel_size;    /* --kernel_size (3): residual kxk conv and hourglass pool */
+    int32_t max_batch;      /* largest B any call will pass */
+    int32_t device;         /* HIP device ordinal */
+    int32_t training;       /* 0: inference only; 1: also allocate saved activations/grads/Adam */
+} dr_config;
+
+int dr_abi_version(void);
+const char* dr_backend(void);                     /* "hip-gfx950" for the product library */
+int dr_create(const dr_config* cfg, dr_handle** out);
+void dr_destroy(dr_handle* h);
+const char* dr_last_error(const dr_handle* h);
+
+/* ---- variables (TF names, HWIO weights; host float32 buffers) ------------------------------- */
+int dr_param_count(const dr_handle* h);
+int dr_param_info(const dr_handle* h, int index, const char** name, int32_t dims[4], int32_t* ndim,
+                  int32_t* trainable);
+int dr_load_param(dr_handle* h, const char* name, const float* host, size_t count);
+int dr_read_param(dr_handle* h, const char* name, float* host, size_t count);
+/* Pack weights for the MFMA kernels, fold eval-mode BatchReNorm; call after loading, before any
+ * forward.  Synchronises. */
+int dr_finalize_params(dr_handle* h, dr_stream stream);
+
+/* ---- pre-processing on the path --------------------------------------------------------------- */
+/* data/preprocess.py:176-187 norm_dm: dm_mm (B,hw,hw,1), com (B,3) -> dm_norm (B,hw,hw,1) */
+int dr_norm_dm(dr_handle* h, int B, const float* dm_mm_dev, const float* com_dev, float* dm_norm_dev,
+               dr_stream stream);
+
+/* ---- inference ---------------------------------------------------------------------------------- */
+/* detect_net(..., is_training=False); fills the LAST stack's maps (hourglass_um_crop_tiny.py:451-455)
+ * when the pointers are non-NULL: hm (B,h,w,J), hm3 (B,h,w,J), um (B,h,w,3J), h = w = in_hw/4. */
+int dr_forward_eval(dr_handle* h, int B, const float* dm_norm_dev, float* hm_dev, float* hm3_dev,
+                    float* um_dev, dr_stream stream);
+/* Maps of any stack of the most recent forward (eval or train), same layouts. */
+int dr_read_maps(dr_handle* h, int B, int stack, float* hm_dev, float* hm3_dev, float* um_dev,
+                 dr_stream stream);
+/* _resume_om + _xyz_estimation + unnorm_xyz_pose on caller-provided maps.
+ * dm_norm (B,hw,hw,1), cfg (B,6)=fx,fy,cx,cy,w,h, com (B,3) -> xyz_mm (B,3J). */
+int dr_vote(dr_handle* h, int B, const float* hm_dev, const float* hm3_dev, const float* um_dev,
+            const float* dm_norm_dev, const float* cfg_dev, const float* com_dev, float* xyz_mm_dev,
+            dr_stream stream);
+/* JointDetectionModel.test (:442-462): forward(eval) + vote without materialising dense maps. */
+int dr_infer(dr_handle* h, int B, const float* dm_norm_dev, const float* cfg_dev, const float* com_dev,
+             float* xyz_mm_dev, dr_stream stream);
+
+/* ---- training (handle created with training=1) -------------------------------------------------- */
+enum { DR_DROPOUT_OFF = 0, DR_DROPOUT_MASK = 1, DR_DROPOUT_RNG = 2 };
+/* detect_net(..., is_training=True): batch-statistics BatchReNorm (updates moving stats, r_max,
+ * d_max, curr_t: slim/ops.py:130-171), dropout 0.5 after the two 512-wide head convs.
+ * dropout_mode MASK: keep_mask_dev = uint8 [num_stack][2][B*h*w*512] (1 = keep, scaled x2);
+ * RNG: counter-based generator keyed by `seed`. */
+int dr_forward_train(dr_handle* h, int B, const float* dm_norm_dev, int dropout_mode,
+                     const uint8_t* keep_mask_dev, uint64_t seed, dr_stream stream);
+/* JointDetectionModel.loss (:323-371) on the maps of the last dr_forward_train: synthesises the
+ * targets (_hm_2d/_hm_3d/_um), writes losses_dev[4] = {hm, hm3, um, reg} (sum over stacks,
+ * l2_loss = sum(x^2)/2) and seeds the gradients of all stacks' maps. */
+int dr_loss(dr_handle* h, int B, const float* dm_norm_dev, const float* pose_mm_dev, const float* cfg_dev,
+            const float* com_dev, float* losses_dev, dr_stream stream);
+/* Back-propagation through the whole graph; ADDS d(total loss)/d(theta), including the L2
+ * regulariser term, into the flat gradient accumulator (train_single_gpu.py:84 accum_op). */
+int dr_backward(dr_handle* h, int B, dr_stream stream);
+int dr_zero_grad(dr_handle* h, dr_stream stream);                       /* reset_op (:83) */
+/* Flat fp32 views in TF trainable-variable creation order (for RCCL all-reduce / checkpoints). */
+int dr_flat_grad(dr_handle* h, float** dev_ptr, size_t* count);
+int dr_flat_param(dr_handle* h, float** dev_ptr, size_t* count);
+/* g = clip(acc / div, -clip, clip); Adam(beta1=0.5, beta2=0.999, eps=1e-8), TF update rule;
+ * step is 1-based (train_single_gpu.py:86-89; hourglass_um_crop_tiny.py:436-439).  Re-packs the
+ * weights for the next forward. */
+int dr_apply_adam(dr_handle* h, float lr, float div, float clip, int64_t step, dr_stream stream);
+
+/* ---- introspection (tests / profiling) ----------------------------------------------------------- */
+/* Post-activation output of conv `scope` (e.g. "Conv_12") of the last forward as dense NHWC. */
+int dr_read_activation(dr_handle* h, const char* scope, int B, float* host, size_t count);
+/* Algorithmic conv FLOPs per crop (forward), SURVEY section 8(d). */
+double dr_conv_flops_per_crop(const dr_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DENSEREG_H_ */

@@ -1,0 +1,36 @@
+/* densereg_debug.h -- test hooks of libdensereg_hip.so.  NOT part of the integration surface:
+ * they exist so that tests/ can drive a single kernel through the C ABI with raw pointers. */
+#ifndef DENSEREG_DEBUG_H_
+#define DENSEREG_DEBUG_H_
+#include "densereg.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One stride-1 SAME convolution through the implicit-GEMM MFMA kernel.
+ * x: (B,H,W,*) with channel stride x_cs (multiple of 4) ; w: HWIO (k,k,Cin,Cout) ; y: channel stride y_cs.
+ * v = conv*scale[n] + shift[n] (NULL = 1 / 0); relu; + res (stride res_cs) ; rows with rowmask[m] < thresh
+ * read as zero; stat (2*Cout doubles, pre-zeroed): per-channel sum / sum of squares of the raw conv.
+ * All pointers are device pointers.  Synchronises the stream. */
+int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, const float* x, int x_cs, const float* w,
+                  const float* scale, const float* shift, int relu, const float* res, int res_cs,
+                  const float* rowmask, float thresh, float* y, int y_cs, double* stat, dr_stream stream);
+
+/* Per-kernel timing with HIP events on the caller's stream (bench.py roofline leg).  While enabled,
+ * every op of the executors is bracketed by two events; dr_profile_read synchronises, aggregates by
+ * kernel, returns one row per kernel that ran, and resets.  flops/bytes are the ALGORITHMIC counts
+ * (SURVEY 8d), not measured traffic. */
+typedef struct dr_kernel_stat {
+    char name[64];
+    int64_t launches;
+    double total_ms;
+    double flops;
+    double bytes;
+} dr_kernel_stat;
+int dr_profile_enable(dr_handle* h, int on);
+int dr_profile_read(dr_handle* h, dr_kernel_stat* out, int max_out, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

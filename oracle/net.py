@@ -94,6 +94,7 @@ class TorchOps(OpsBase):
         self.dtype = dtype
         self.bn_updates: Dict[str, torch.Tensor] = {}
         self.record = record        # name -> NHWC numpy of every conv output (post activation)
+        self._producer = {}         # id(tensor) -> (conv name, tensor) for '+res' records
 
     def channels(self, x):
         return x.shape[1]
@@ -140,10 +141,20 @@ class TorchOps(OpsBase):
             y = torch.relu(y)
         if self.record is not None:
             self.record[name] = y.detach().permute(0, 2, 3, 1).contiguous().numpy()
+            self._producer[id(y)] = (name, y)
         return y
 
     def add(self, a, b):
-        return a + b
+        out = a + b
+        if self.record is not None:
+            # the HIP engine fuses the residual add into the producing conv's epilogue: also record
+            # '<conv>+res' so tests can compare what the engine stores for that conv.
+            for t in (a, b):
+                ent = self._producer.get(id(t))
+                if ent is not None and ent[1] is t:
+                    self.record[ent[0] + '+res'] = out.detach().permute(0, 2, 3, 1).contiguous().numpy()
+                    break
+        return out
 
     def max_pool(self, x, k, s):
         H, W = x.shape[2], x.shape[3]

@@ -137,7 +137,7 @@ def resume_om(hm3: np.ndarray, um: np.ndarray) -> np.ndarray:
 # --------------------------------------------------------------------------------------
 NUM_PT = 5
 MS_ITERS = 10
-MS_BANDWIDTH = f32(0.4)
+MS_BANDWIDTH = 0.4          # python float in the reference (:775); -1/(2*bw*bw) -> f32(-3.125)
 
 
 def top_k_indices(v: np.ndarray, k: int) -> np.ndarray:

@@ -1,0 +1,30 @@
+import os
+import sys
+import warnings
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+warnings.filterwarnings('ignore', message='Converting a tensor with requires_grad')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def emu():
+    from tests.common import EmuBackend
+    return EmuBackend()
+
+
+@pytest.fixture(scope='session')
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail('-m gpu tests need a GPU: the HIP path has no fallback')
+    from tests.common import GpuBackend
+    return GpuBackend()

@@ -1,0 +1,178 @@
+"""Parity of the HIP forward path (conv kernel, whole network, vote) against the CPU oracle and the
+committed golden vectors, through the C ABI.
+
+Every test runs twice: ``[emu]`` = the same kernel sources on the host-fiber emulator (CPU, catches
+index/layout bugs without a device) and ``[gpu]`` = the real library on an MI355X (``-m gpu``).
+Tolerances: fp32 everywhere; conv vs an fp64 reference 2e-5 relative to the tensor scale (fp32
+accumulation-order noise), maps 2e-4 absolute, xyz 1e-3 mm on identical maps (exp() ulps only),
+and BASELINE.json's <= 0.1 mm mean-joint-error delta end to end.
+"""
+import numpy as np
+import pytest
+
+from tests.common import e2e_case, golden, ref_conv2d
+
+BACKENDS = [pytest.param('emu'), pytest.param('gpu', marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def be(request):
+    return request.getfixturevalue(request.param)
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+# ---------------------------------------------------------------------------------------------
+# conv kernel
+# ---------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k      (ragged channel counts of the real net: 65, 131, 515, 80, 5J ...)
+    (1, 8, 8, 16, 32, 1),
+    (2, 6, 5, 65, 65, 3),
+    (1, 16, 16, 131, 128, 1),
+    (3, 4, 4, 20, 70, 3),
+    (2, 2, 2, 128, 64, 1),
+    (1, 8, 8, 160, 256, 1),
+    (1, 4, 4, 515, 512, 1),
+    (1, 9, 7, 80, 48, 3),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_fused_epilogue(be, case):
+    B, H, W, Cin, Cout, k = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
+    mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if k == 1 else None
+    y, st = be.conv2d(x, w, scale, shift, True, res, mask, -0.5, want_stats=True)
+    yr, raw = ref_conv2d(x, w, scale, shift, True, res, mask, -0.5)
+    assert _rel(y, yr) < 2e-5
+    np.testing.assert_allclose(st[0], raw.sum((0, 1, 2)), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(st[1], (raw ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-4)
+
+
+def test_conv_transpose_detecting(be):
+    """A = identity-like input with an ASYMMETRIC weight matrix: catches a swapped MFMA C/D layout."""
+    Cin = Cout = 64
+    x = np.zeros((1, 8, 8, Cin), np.float32)
+    for m in range(64):
+        x.reshape(64, Cin)[m, m] = 1.0                        # pixel m has a one in channel m
+    w = (np.arange(Cin)[:, None] * 100 + np.arange(Cout)[None, :]).astype(np.float32).reshape(1, 1, Cin, Cout)
+    y = be.conv2d(x, w)
+    np.testing.assert_array_equal(y.reshape(64, Cout), w.reshape(Cin, Cout))     # exact in fp32
+
+
+def test_conv_golden_vectors(be):
+    g = golden('conv_cases.npz')
+    for i in range(3):
+        y = be.conv2d(g['x%d' % i], g['w%d' % i], g['scale%d' % i], g['shift%d' % i], True, g['res%d' % i])
+        assert _rel(y, g['y%d' % i]) < 2e-5
+
+
+def test_conv_plain_linear(be):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 5, 5, 24)).astype(np.float32)
+    w = rng.standard_normal((3, 3, 24, 40)).astype(np.float32)
+    y = be.conv2d(x, w)
+    yr, _ = ref_conv2d(x, w)
+    assert _rel(y, yr) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# whole network (config-1 stand-in: ICVL S=1 F=64 B=1) against golden + oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def case1():
+    return e2e_case()
+
+
+def _net_setup(be, cfg, params, B):
+    h = be.handle(cfg, B)
+    from oracle.graph import param_specs
+    assert [(n, tuple(s), t) for n, s, t in h.param_infos()] == [(n, tuple(s), t) for n, s, t in param_specs(cfg)]
+    h.load_params(params)
+    h.call('dr_finalize_params', be.stream)
+    return h
+
+
+def test_network_forward_and_vote_config1(be, case1):
+    from oracle import net, pose
+    from oracle.graph import conv_specs
+    cfg, params, g = case1
+    h = _net_setup(be, cfg, params, 1)
+    assert abs(h.conv_flops_per_crop() / 1e9 - 4.262) < 1e-3
+    dm, cfgs, coms = g['dm'], g['cfg'], g['com']
+    ndm = be.norm_dm(h, dm, coms)
+    np.testing.assert_array_equal(ndm, pose.norm_dm(dm, coms))
+    hm, hm3, um = be.forward_eval(h, ndm)
+    # committed golden (oracle) maps, stored on a ::2 grid
+    assert np.abs(hm[:, ::2, ::2] - g['hm']).max() < 2e-4
+    assert np.abs(hm3[:, ::2, ::2] - g['hm3']).max() < 2e-4
+    assert np.abs(um[:, ::2, ::2] - g['um']).max() < 2e-4
+    # every conv output against the oracle's record
+    rec = {}
+    net.forward_eval(cfg, params, ndm, record=rec)
+    worst = 0.0
+    for c in conv_specs(cfg):
+        a = be.read_activation(h, c.name, (1, c.h_out, c.w_out, c.cout))
+        r = rec.get(c.name + '+res', rec[c.name])
+        worst = max(worst, _rel(a, r))
+        assert _rel(a, r) < 1e-4, c.name
+    # vote on identical maps, then the fused infer path end to end
+    xyz = be.vote(h, hm, hm3, um, ndm, cfgs, coms)
+    ref_same = pose.estimate_pose_mm(hm, hm3, um, ndm, cfgs, coms)
+    assert np.abs(xyz - ref_same).max() < 1e-3
+    xyz2 = be.infer(h, ndm, cfgs, coms)
+    assert pose.mean_jnt_error(xyz2, g['xyz']) <= 0.1           # BASELINE.json tolerance
+    assert np.abs(xyz2 - g['xyz']).max() < 0.05
+    h.close()
+
+
+def test_vote_crafted_cases(be):
+    """Planted peaks / exact ties / negative weights / out-of-range re-projection / all-background."""
+    from oracle.graph import NetConfig
+    g = golden('vote_cases.npz')
+    hm, hm3, um = (g[k].astype(np.float32) for k in ('hm', 'hm3', 'um'))
+    B, m, _, J = hm.shape
+    ndm = np.repeat(np.repeat(g['tiny'], 4, axis=1), 4, axis=2).astype(np.float32)
+    h = be.handle(NetConfig(1, 8, J), B)
+    xyz = be.vote(h, hm, hm3, um, ndm, g['cfg'], g['com'])
+    np.testing.assert_allclose(xyz, g['xyz'], atol=2e-3, rtol=0)
+    assert np.isfinite(xyz).all()
+    # exact-tie sample: the five candidates are the first five pixels in row-major order
+    assert g['idx'][4].tolist() == [[0, 1, 2, 3, 4]] * J
+    h.close()
+
+
+def test_abi_error_behaviour(be):
+    """Argument checking mirrors the reference's error behaviour (ValueError on unknown input size,
+    um_v1.py:106-107) plus the C-ABI contract of SURVEY 8b."""
+    from densereg_amd import _lib
+    from oracle.graph import NetConfig
+    with pytest.raises(_lib.DenseRegError) as e:
+        _lib.Handle(be.lib, 1, 8, 2, 100, 3, 1, 0, False)
+    assert e.value.code == -2 and 'unknown input depth map shape' in str(e.value)
+    with pytest.raises(_lib.DenseRegError):
+        _lib.Handle(be.lib, 0, 8, 2, 128, 3, 1, 0, False)
+    h = be.handle(NetConfig(1, 8, 2), 1)
+    x = be.empty((2, 128, 128, 1))
+    with pytest.raises(_lib.DenseRegError) as e:            # forward before finalize
+        h.call('dr_forward_eval', 1, be.ptr(x), None, None, None, be.stream)
+    assert e.value.code == -3
+    h.call('dr_finalize_params', be.stream)
+    with pytest.raises(_lib.DenseRegError) as e:            # B > max_batch
+        h.call('dr_forward_eval', 2, be.ptr(x), None, None, None, be.stream)
+    assert e.value.code == -1
+    with pytest.raises(_lib.DenseRegError):
+        h.call('dr_load_param', b'no/such/var', x.ctypes.data if hasattr(x, 'ctypes') else 1, 1)
+    bad = np.zeros(3, np.float32)
+    with pytest.raises(_lib.DenseRegError):                 # wrong element count
+        h.call('dr_load_param', b'Conv/weights', bad.ctypes.data, 3)
+    assert h.lib.dr_forward_eval(h._h, 1, None, None, None, None, None) == -1      # null input
+    h.close()

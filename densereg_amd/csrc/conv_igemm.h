@@ -34,8 +34,19 @@ struct ConvParams {
     const float* res; int res_cs; int res_coff;      // nullable
     const float* rowmask; float mask_thresh;         // nullable: A row zeroed where rowmask[m] < thresh
     const unsigned char* drop;                       // nullable: keep mask [M][Cout], kept -> x2
+    int drop_rng; unsigned long long drop_seed;      // drop_rng != 0: counter-based keep bit instead of `drop`
+    const float* out_rowmask; float out_mask_thresh; // nullable: rows with out_rowmask[m] < thresh are not written
     double* stat_sum; double* stat_sq;               // nullable: per-channel moments of acc
 };
+
+// stateless keep bit for dropout(0.5): splitmix64 finaliser of (seed, element index)
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (z >> 17) & 1ull;
+}
 
 template <int BM, int BN, int WM, int WN>
 struct ConvTile {
@@ -200,13 +211,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * T::kWTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (m < M && n_ok) {
+                if (m < M && n_ok && !(p.out_rowmask && p.out_rowmask[m] < p.out_mask_thresh)) {
                     const float raw = acc[i][j][r];
                     s1 += (double)raw;
                     s2 += (double)raw * (double)raw;
                     float v = raw * sc + sh;
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.drop) v = p.drop[(long)m * p.Cout + n] ? v * 2.f : 0.f;
+                    else if (p.drop_rng) v = dropout_keep(p.drop_seed, (unsigned long long)m * p.Cout + n) ? v * 2.f : 0.f;
                     if (p.res) v += p.res[(long)m * p.res_cs + p.res_coff + n];
                     p.y[(long)m * p.y_cs + p.y_coff + n] = v;
                 }

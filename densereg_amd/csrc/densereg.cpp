@@ -6,6 +6,7 @@
 #include <map>
 
 #include "conv_igemm.h"
+#include "conv_wgrad.h"
 #include "kernels_misc.h"
 #include "net.h"
 #include "train_kernels.h"
@@ -316,8 +317,12 @@ static void free_all(dr_handle* h) {
     for (void* p : {(void*)h->flat_param, (void*)h->flat_grad, (void*)h->adam_m, (void*)h->adam_v, (void*)h->flat_state,
                     (void*)h->shadow, (void*)h->wp, (void*)h->wpT, (void*)h->fold, (void*)h->stats, (void*)h->bnc,
                     (void*)h->act_arena, (void*)h->grad_arena, (void*)h->scratch, (void*)h->tiny, (void*)h->tiny_ext,
-                    (void*)h->losses})
+                    (void*)h->losses, (void*)h->reg_segs, (void*)h->loss_acc, (void*)h->bn_coef, (void*)h->wg_partial})
         if (p) rt::dfree(p);
+}
+
+namespace {
+int alloc_training_state(dr_handle* h);
 }
 
 // ==============================================================================================
@@ -421,6 +426,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         ok = ok && h->stats;
         h->n_gact = nact;
         alloc_f(h->grad_arena, nact);
+        if (ok && alloc_training_state(h)) ok = false;
     }
     if (!ok) {
         free_all(h);
@@ -513,7 +519,13 @@ int dr_load_param(dr_handle* h, const char* name, const float* host, size_t coun
     if (p->kind == PK_CURRT) { c.curr_t = host[0]; return DR_OK; }
     if (rt::h2d(param_dev_ptr(h, *p), host, count * sizeof(float), nullptr)) DR_FAIL(h, DR_E_DEVICE, "h2d failed");
     rt::sync_stream(nullptr);
-    if (h->cfg.training && (p->kind == PK_MMEAN || p->kind == PK_MVAR)) c.shadow_step = 0;
+    if (h->cfg.training && (p->kind == PK_MMEAN || p->kind == PK_MVAR)) {
+        // Restoring moving stats WITHOUT the zero-debias slot variables (<var>/biased, <var>/local_step) =
+        // a fresh shadow, exactly what TF1.3 does when a checkpoint lacks them (DESIGN.md "BatchReNorm state").
+        c.shadow_step = 0;
+        rt::memset_async(h->shadow + c.shadow_off, 0, 2 * (size_t)c.cout * sizeof(float), nullptr);
+        rt::sync_stream(nullptr);
+    }
     h->finalized = false;
     return DR_OK;
 }
@@ -569,6 +581,7 @@ int dr_finalize_params(dr_handle* h, dr_stream stream) {
     if (rt::sync_stream(s)) DR_FAIL(h, DR_E_DEVICE, "dr_finalize_params: stream sync failed");
     DR_CHECK_LAUNCH(h);
     h->finalized = true;
+    h->fold_is_eval = true;
     return DR_OK;
 }
 
@@ -664,6 +677,11 @@ static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s
     if (!h->finalized) DR_FAIL(h, DR_E_STATE, "forward before dr_finalize_params");
     if (B < 1 || B > h->cfg.max_batch) DR_FAIL(h, DR_E_INVALID, "batch %d outside [1, max_batch=%d]", B, h->cfg.max_batch);
     h->dm_in = dm;
+    if (!h->fold_is_eval) {          // a training forward overwrote the per-layer scale/shift
+        int rc = fold_bn(h, s);
+        if (rc) return rc;
+        h->fold_is_eval = true;
+    }
     for (const Op& op : h->ops) {
         int rc = (op.kind == OP_CONV || op.kind == OP_STEM) ? run_conv_eval(h, op, B, s) : run_simple_op(h, op, B, s);
         if (rc) return rc;

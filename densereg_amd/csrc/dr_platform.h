@@ -71,5 +71,5 @@ inline float event_elapsed_ms(Event a, Event b) { float ms = 0.f; (void)hipEvent
 typedef float dr_f32x16 __attribute__((ext_vector_type(16)));
 typedef float dr_f32x4 __attribute__((ext_vector_type(4)));
 
-static inline int dr_ceil_div(int a, int b) { return (a + b - 1) / b; }
-static inline int dr_round_up(int a, int b) { return dr_ceil_div(a, b) * b; }
+__host__ __device__ static inline int dr_ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int dr_round_up(int a, int b) { return dr_ceil_div(a, b) * b; }

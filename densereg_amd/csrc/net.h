@@ -86,6 +86,7 @@ static const char* const kKernelNames[KID_COUNT] = {
     "upsample_add", "uvd", "copy_channels", "vote", "batch_renorm", "conv_wgrad", "eltwise_bwd", "loss", "adam"};
 
 struct ProfRecord { rt::Event a, b; int kid; double flops; double bytes; };
+struct RegSeg;
 
 }  // namespace dr
 
@@ -126,4 +127,11 @@ struct dr_handle {
     double flops_per_crop = 0.0;
     bool profiling = false;
     std::vector<dr::ProfRecord> prof;
+    // training-only state
+    dr::RegSeg* reg_segs = nullptr; int n_reg = 0;        // weight segments with weight_decay > 0
+    double* loss_acc = nullptr;                            // 4 doubles: hm, hm3, um, reg
+    float* bn_coef = nullptr;                              // 3*max(cout) floats (BatchReNorm backward)
+    float* wg_partial = nullptr; size_t n_wg_partial = 0;  // split-K slabs of the weight gradient
+    bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold
+    const float* dm_train = nullptr;                       // input of the last dr_forward_train
 };

@@ -1,7 +1,406 @@
-// train_kernels.h -- training-side kernels (BatchReNorm batch statistics, backward passes, loss, Adam).
+// train_kernels.h -- training-side kernels: train-mode BatchReNorm, backward passes, loss, Adam.
+//
+// Reference semantics (paths relative to the reference tree):
+//   BatchReNorm train mode      network/slim/ops.py:130-171
+//   loss + target synthesis     model/hourglass_um_crop_tiny.py:193-274, 323-371
+//   accumulate / clip / Adam    model/train_single_gpu.py:69-89 ; hourglass_um_crop_tiny.py:436-439
+// Gradients are derived by hand from those forward definitions (TF would autodiff the same graph);
+// tests/ check them against torch autograd through the CPU oracle.
 #pragma once
 #include "dr_platform.h"
 #include "kernels_misc.h"
 
 namespace dr {
+
+// ------------------------------------------------------------------------------------------------
+// BatchReNorm, train mode.  One thread per channel.
+//   mean/var: biased moments of the raw conv output (fp64 sums from the conv epilogue)
+//   r = clip(std/std_mov, 1/r_max, r_max), d = clip((mean-mean_mov)/std_mov, +-d_max)   [stop-gradient]
+//   y = ((x-mean)*inv_std*r + d)*gamma + beta  ==  x*scale + shift
+//   moving stats: "read old, then update" (SURVEY Appendix C.2); assign_moving_average(decay=.99) with
+//   [TF1.3-semantics] zero_debias=True: biased -= (biased-value)*(1-decay); var = biased/(1-decay^step).
+// ------------------------------------------------------------------------------------------------
+struct BnFinalizeParams {
+    const double* sum; const double* sq; double count;
+    const float* beta; const float* gamma;
+    float* mm; float* mv;             // moving mean / variance (updated in place)
+    float* shadow_mean; float* shadow_var; int shadow_step;   // step AFTER this update (>=1); 0 = plain EMA
+    float r_max, d_max, eps, decay;
+    float* scale; float* shift;       // out: fused multiply-add of the normalisation
+    float* bnc;                       // out: [4][C] mean, inv_std, r, d (for the backward pass)
+    int C;
+};
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinalizeParams p) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.C) return;
+    const double mean_d = p.sum[c] / p.count;
+    double var_d = p.sq[c] / p.count - mean_d * mean_d;
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d, var = (float)var_d;
+    const float inv_std = 1.0f / sqrtf(var + p.eps);
+    const float std_b = sqrtf(var + p.eps);
+    const float mstd = sqrtf(p.mv[c] + p.eps);
+    float r = std_b / mstd;
+    r = fminf(fmaxf(r, 1.0f / p.r_max), p.r_max);
+    float d = (mean - p.mm[c]) / mstd;
+    d = fminf(fmaxf(d, -p.d_max), p.d_max);
+    const float g = p.gamma[c];
+    const float sc = inv_std * r;
+    p.scale[c] = sc * g;
+    p.shift[c] = (d - mean * sc) * g + p.beta[c];
+    p.bnc[0 * p.C + c] = mean;
+    p.bnc[1 * p.C + c] = inv_std;
+    p.bnc[2 * p.C + c] = r;
+    p.bnc[3 * p.C + c] = d;
+    // moving statistics
+    const float om = 1.0f - p.decay;
+    if (p.shadow_step > 0) {
+        const float bm = p.shadow_mean[c] - (p.shadow_mean[c] - mean) * om;
+        const float bv = p.shadow_var[c] - (p.shadow_var[c] - var) * om;
+        p.shadow_mean[c] = bm;
+        p.shadow_var[c] = bv;
+        const float corr = 1.0f - powf(p.decay, (float)p.shadow_step);
+        p.mm[c] = bm / corr;
+        p.mv[c] = bv / corr;
+    } else {
+        p.mm[c] = p.mm[c] - (p.mm[c] - mean) * om;
+        p.mv[c] = p.mv[c] - (p.mv[c] - var) * om;
+    }
+}
+
+// out(m,c) = relu(raw(m,c)*scale[c] + shift[c]) + res(m,c)        thread = (row, group of 4 channels)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* raw, int raw_cs, const float* scale, const float* shift,
+                                                       int relu, View res, View out, long M, int C) {
+    const int c4n = (C + 3) / 4;
+    const long total = M * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = int(i % c4n) * 4;
+        const long m = i / c4n;
+        const float4 x = *reinterpret_cast<const float4*>(raw + m * raw_cs + c0);
+        float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            if (c < C) {
+                float y = v[k] * scale[c] + shift[c];
+                if (relu) y = fmaxf(y, 0.f);
+                if (res.p) y += res.p[m * res.cs + res.coff + c];
+                out.p[m * out.cs + out.coff + c] = y;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchReNorm backward.
+//   out = gamma*(r*yhat + d) + beta, yhat = (x-mean)*inv_std, g = dOut * [out_pre_relu > 0]
+//   dbeta = sum g ; dgamma = r*sum(g*yhat) + d*sum(g)
+//   dx = gamma*r*inv_std * (g - mean(g) - yhat*mean(g*yhat))
+// reduce: per-channel sum g, sum g*yhat (fp64, one atomic per block and channel)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(View dout, const float* raw, int raw_cs, const float* scale,
+                                                            const float* shift, const float* bnc, int relu, long M, int C,
+                                                            double* sum_g, double* sum_gy) {
+    __shared__ double s1[256];
+    __shared__ double s2[256];
+    const int tid = threadIdx.x;
+    const int cpb = C < 256 ? C : 256;
+    const int rows_par = 256 / cpb;
+    for (int c0 = 0; c0 < C; c0 += cpb) {
+        const int c = c0 + tid % cpb;
+        const int rp = tid / cpb;
+        double a = 0.0, b = 0.0;
+        if (rp < rows_par && c < C) {
+            const float sc = scale[c], sh = shift[c], mean = bnc[c], inv_std = bnc[C + c];
+            for (long m = (long)blockIdx.x * rows_par + rp; m < M; m += (long)gridDim.x * rows_par) {
+                const float x = raw[m * raw_cs + c];
+                float g = dout.p[m * dout.cs + dout.coff + c];
+                if (relu && !(x * sc + sh > 0.f)) g = 0.f;
+                const float yh = (x - mean) * inv_std;
+                a += (double)g;
+                b += (double)g * (double)yh;
+            }
+        }
+        s1[tid] = a;
+        s2[tid] = b;
+        __syncthreads();
+        if (tid < cpb && c0 + tid < C) {
+            double ta = 0.0, tb = 0.0;
+            for (int r = 0; r < rows_par; ++r) { ta += s1[r * cpb + tid]; tb += s2[r * cpb + tid]; }
+            atomicAdd(&sum_g[c0 + tid], ta);
+            atomicAdd(&sum_gy[c0 + tid], tb);
+        }
+        __syncthreads();
+    }
+}
+
+// per channel: parameter gradients (accumulated) and the three dx coefficients
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* sum_g, const double* sum_gy, double count,
+                                                              const float* gamma, const float* bnc, float* dbeta,
+                                                              float* dgamma, float* coef, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sg = (float)sum_g[c], sgy = (float)sum_gy[c];
+    const float inv_std = bnc[C + c], r = bnc[2 * C + c], d = bnc[3 * C + c];
+    dbeta[c] += sg;
+    dgamma[c] += r * sgy + d * sg;
+    coef[0 * C + c] = gamma[c] * r * inv_std;
+    coef[1 * C + c] = (float)(sum_g[c] / count);
+    coef[2 * C + c] = (float)(sum_gy[c] / count);
+}
+
+// draw(m,c) = c1*(g - c2 - yhat*c3)     (draw dense, channel stride = raw_cs; pad channels zeroed)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dout, const float* raw, int raw_cs, const float* scale,
+                                                           const float* shift, const float* bnc, const float* coef, int relu,
+                                                           float* draw, long M, int C) {
+    const int c4n = raw_cs / 4;
+    const long total = M * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = int(i % c4n) * 4;
+        const long m = i / c4n;
+        const float4 x4 = *reinterpret_cast<const float4*>(raw + m * raw_cs + c0);
+        const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            o[k] = 0.f;
+            if (c < C) {
+                float g = dout.p[m * dout.cs + dout.coff + c];
+                if (relu && !(xv[k] * scale[c] + shift[c] > 0.f)) g = 0.f;
+                const float yh = (xv[k] - bnc[c]) * bnc[C + c];
+                o[k] = coef[c] * (g - coef[C + c] - yh * coef[2 * C + c]);
+            }
+        }
+        *reinterpret_cast<float4*>(draw + m * raw_cs + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// bias convs: g(m,c) = dOut(m,c) * factor * [out(m,c) > 0 if relu]  -> dense scratch (stride gcs), pads zero
+__global__ __launch_bounds__(256) void act_bwd_kernel(View dout, View out, int relu, float factor, float* g, int gcs, long M,
+                                                      int C) {
+    const int c4n = gcs / 4;
+    const long total = M * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = int(i % c4n) * 4;
+        const long m = i / c4n;
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            o[k] = 0.f;
+            if (c < C) {
+                float v = dout.p[m * dout.cs + dout.coff + c] * factor;
+                if (relu && !(out.p[m * out.cs + out.coff + c] > 0.f)) v = 0.f;
+                o[k] = v;
+            }
+        }
+        *reinterpret_cast<float4*>(g + m * gcs + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dst[c] += sum_m g(m,c)    (bias gradient)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* g, int cs, int coff, long M, int C, float* dst) {
+    __shared__ double s1[256];
+    const int tid = threadIdx.x;
+    const int cpb = C < 256 ? C : 256;
+    const int rows_par = 256 / cpb;
+    for (int c0 = 0; c0 < C; c0 += cpb) {
+        const int c = c0 + tid % cpb;
+        const int rp = tid / cpb;
+        double a = 0.0;
+        if (rp < rows_par && c < C)
+            for (long m = (long)blockIdx.x * rows_par + rp; m < M; m += (long)gridDim.x * rows_par) a += (double)g[m * cs + coff + c];
+        s1[tid] = a;
+        __syncthreads();
+        if (tid < cpb && c0 + tid < C) {
+            double ta = 0.0;
+            for (int r = 0; r < rows_par; ++r) ta += s1[r * cpb + tid];
+            atomicAdd(&dst[c0 + tid], (float)ta);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Max-pool backward: route dOut to the first maximum of the window (scan order ky, kx; strict >),
+// the convention of torch's max_pool2d which the oracle's autograd follows.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* x, int x_cs, int x_coff, float* dx, int B, int H, int W,
+                                                          int C, int k, int pad_t, int pad_l, const float* dy, int y_cs,
+                                                          int y_coff, int Ho, int Wo) {
+    const long total = (long)B * Ho * Wo * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = int(i % C);
+        const long pix = i / C;
+        const int ox = int(pix % Wo);
+        const int oy = int((pix / Wo) % Ho);
+        const int b = int(pix / ((long)Wo * Ho));
+        float best = -INFINITY;
+        long best_off = -1;
+        for (int ky = 0; ky < k; ++ky) {
+            const int iy = oy * 2 + ky - pad_t;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ix = ox * 2 + kx - pad_l;
+                if (ix < 0 || ix >= W) continue;
+                const long off = ((long)(b * H + iy) * W + ix) * x_cs + x_coff + c;
+                const float v = x[off];
+                if (v > best || best_off < 0) { best = v; best_off = off; }
+            }
+        }
+        if (best_off >= 0) atomicAdd(&dx[best_off], dy[pix * y_cs + y_coff + c]);
+    }
+}
+
+// upsample-add backward: da += dout ; dlo(y/2,x/2) += sum of the 2x2 block of dout.  thread = (lo pixel, channel)
+__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(View dout, View da, View dlo, int B, int H, int W, int C) {
+    const int h2 = H / 2, w2 = W / 2;
+    const long total = (long)B * h2 * w2 * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = int(i % C);
+        const long lp = i / C;
+        const int lx = int(lp % w2);
+        const int ly = int((lp / w2) % h2);
+        const int b = int(lp / ((long)w2 * h2));
+        float s = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const long pix = ((long)b * H + ly * 2 + dy) * W + lx * 2 + dx;
+                const float g = dout.p[pix * dout.cs + dout.coff + c];
+                da.p[pix * da.cs + da.coff + c] += g;
+                s += g;
+            }
+        dlo.p[lp * dlo.cs + dlo.coff + c] += s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Loss: target synthesis + l2 losses + gradient seeds for every stack, one thread per map pixel.
+// fp32 in the reference's op order (contraction off), see oracle/pose.py make_targets.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxStack = 8;
+struct LossParams {
+    View hm[kMaxStack], hm3[kMaxStack], um[kMaxStack];        // predictions
+    View dhm[kMaxStack], dhm3[kMaxStack], dum[kMaxStack];     // gradient seeds (written)
+    int S, B, h, w, J;
+    const float* tiny; const float* pose; const float* cfg; const float* com;
+    double* acc;                                              // [3] hm, hm3, um (sum x^2 / 2)
+};
+
+__global__ __launch_bounds__(256) void loss_kernel(const LossParams p) {
+#pragma clang fp contract(off)
+    __shared__ double red[3][4];
+    const int npix = p.h * p.w;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double l_hm = 0.0, l_hm3 = 0.0, l_um = 0.0;
+    if (i < p.B * npix) {
+        const int b = i / npix, px = i % npix;
+        const float* cfg = p.cfg + b * 6;
+        const float cx0 = p.com[b * 3 + 0], cy0 = p.com[b * 3 + 1], cz0 = p.com[b * 3 + 2];
+        const float w_ratio = cfg[4] / (float)p.w, h_ratio = cfg[5] / (float)p.h;
+        const float fx = cfg[0] / w_ratio, fy = cfg[1] / h_ratio, cx = cfg[2] / w_ratio, cy = cfg[3] / h_ratio;
+        const float xx = (float)(px % p.w), yy = (float)(px / p.w);
+        // point cloud at this pixel (preprocess.py:202-225)
+        const float t = p.tiny[i];
+        const float min_depth = cz0 - 300.0f * 0.5f, max_depth = cz0 + 300.0f * 0.5f;
+        const float zz = (t < -0.99f) ? max_depth : (t * 300.0f + min_depth);
+        float X = (xx - cx) * (zz / fx);
+        float Y = (yy - cy) * (zz / fy);
+        X = (X - cx0) / 100.0f;
+        Y = (Y - cy0) / 100.0f;
+        const float Z = (zz - cz0) / 100.0f;
+        for (int j = 0; j < p.J; ++j) {
+            const float* ps = p.pose + (long)b * 3 * p.J + 3 * j;
+            // 2D cone (:225-242)
+            const float u = ps[0] * fx / ps[2] + cx;
+            const float v = ps[1] * fy / ps[2] + cy;
+            const float du = xx - u, dv = yy - v;
+            const float gt_hm = fmaxf(4.0f - sqrtf(du * du + dv * dv), 0.0f) / 4.0f;
+            // 3D offsets (:338-346)
+            const float ox = (ps[0] - cx0) / 100.0f - X;
+            const float oy = (ps[1] - cy0) / 100.0f - Y;
+            const float oz = (ps[2] - cz0) / 100.0f - Z;
+            const float dist = sqrtf((ox * ox + oy * oy) + oz * oz);
+            const float gt_hm3 = fmaxf((0.8f - dist) / 0.8f, 0.0f);
+            const float d3 = 0.8f - gt_hm3 * 0.8f;
+            const bool near = d3 < (0.8f - 1e-2f);
+            const float ux = near ? ox / d3 : 0.0f, uy = near ? oy / d3 : 0.0f, uz = near ? oz / d3 : 0.0f;
+            for (int s = 0; s < p.S; ++s) {
+                const long m = i;
+                const float e1 = p.hm[s].p[m * p.hm[s].cs + p.hm[s].coff + j] - gt_hm;
+                const float e2 = p.hm3[s].p[m * p.hm3[s].cs + p.hm3[s].coff + j] - gt_hm3;
+                const float* um = p.um[s].p + m * p.um[s].cs + p.um[s].coff + 3 * j;
+                const float e3 = um[0] - ux, e4 = um[1] - uy, e5 = um[2] - uz;
+                p.dhm[s].p[m * p.dhm[s].cs + p.dhm[s].coff + j] = e1;
+                p.dhm3[s].p[m * p.dhm3[s].cs + p.dhm3[s].coff + j] = e2;
+                float* dum = p.dum[s].p + m * p.dum[s].cs + p.dum[s].coff + 3 * j;
+                dum[0] = e3; dum[1] = e4; dum[2] = e5;
+                l_hm += 0.5 * (double)e1 * e1;
+                l_hm3 += 0.5 * (double)e2 * e2;
+                l_um += 0.5 * ((double)e3 * e3 + (double)e4 * e4 + (double)e5 * e5);
+            }
+        }
+    }
+    // block reduction: wave shuffle, then 4 waves through LDS
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        l_hm += __shfl_xor(l_hm, m);
+        l_hm3 += __shfl_xor(l_hm3, m);
+        l_um += __shfl_xor(l_um, m);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = l_hm; red[1][wave] = l_hm3; red[2][wave] = l_um; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const double s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        atomicAdd(&p.acc[threadIdx.x], s);
+    }
+}
+
+// L2 regulariser (losses.py:56-72): one block per weight segment; value -> acc[3], gradient wd*w -> grad
+struct RegSeg { long off; long n; float wd; };
+__global__ __launch_bounds__(256) void reg_loss_kernel(const float* param, const RegSeg* segs, double* acc) {
+    __shared__ double red[4];
+    const RegSeg sg = segs[blockIdx.x];
+    double a = 0.0;
+    for (long i = threadIdx.x; i < sg.n; i += 256) { const double w = param[sg.off + i]; a += w * w; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&acc[3], (double)sg.wd * 0.5 * (red[0] + red[1] + red[2] + red[3]));
+}
+__global__ __launch_bounds__(256) void reg_grad_kernel(const float* param, float* grad, const RegSeg* segs, int nseg) {
+    for (int s = blockIdx.y; s < nseg; s += gridDim.y) {
+        const RegSeg sg = segs[s];
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < sg.n; i += (long)gridDim.x * 256)
+            grad[sg.off + i] += sg.wd * param[sg.off + i];
+    }
+}
+__global__ void losses_out_kernel(const double* acc, float* out) {
+    if (threadIdx.x < 4) out[threadIdx.x] = (float)acc[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused accumulate-average / clip / Adam over the flat buffers (train_single_gpu.py:86-89).
+//   g = clip(acc/div, +-clip) ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; theta -= lr_t m/(sqrt(v)+eps)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* param, const float* grad, float* m, float* v, long n, float div,
+                                                   float clip, float lr_t, float b1, float b2, float eps) {
+#pragma clang fp contract(off)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float g = grad[i] / div;
+        g = fminf(fmaxf(g, -clip), clip);
+        const float mi = b1 * m[i] + (1.0f - b1) * g;
+        const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        param[i] = param[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
 }  // namespace dr

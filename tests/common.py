@@ -194,3 +194,32 @@ def e2e_case():
     np.testing.assert_allclose(psum, g['param_checksum'], rtol=1e-5,
                                err_msg='regenerated test parameters drifted from the committed checksum')
     return cfg, params, g
+
+
+# ---- raw access to library-owned buffers (flat gradient / parameter views) ----------------------
+def _flat_rw(be, addr, n):
+    """numpy-like accessor pair (read(), write(a)) over n float32 at device address `addr`."""
+    if be.name == 'emu':
+        arr = np.ctypeslib.as_array((C.c_float * n).from_address(addr))
+        return (lambda: arr.copy()), (lambda a: arr.__setitem__(slice(None), a))
+    from densereg_amd.engine import _as_tensor
+    t = _as_tensor(addr, n, be.device)
+
+    def write(a):
+        t.copy_(be.torch.from_numpy(np.ascontiguousarray(a, np.float32)))
+        be.sync()
+    return (lambda: (be.sync(), t.cpu().numpy())[1]), write
+
+
+def flat_grads_by_name(be, h, cfg):
+    from oracle.graph import param_specs
+    addr, n = h.flat('grad')
+    flat = _flat_rw(be, addr, n)[0]()
+    out, off = {}, 0
+    for name, shape, tr in param_specs(cfg):
+        if tr:
+            cnt = int(np.prod(shape))
+            out[name] = flat[off:off + cnt].reshape(shape).copy()
+            off += cnt
+    assert off == n
+    return out

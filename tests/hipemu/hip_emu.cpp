@@ -3,6 +3,8 @@
 
 #include <sys/mman.h>
 
+#include <condition_variable>
+
 #if !defined(__x86_64__)
 #error "hipemu context switch is written for x86-64"
 #endif
@@ -74,6 +76,7 @@ static void prepare_fiber(Fiber& f) {
     for (int i = 3; i <= 8; ++i) s[-i] = nullptr;     // rbp rbx r12 r13 r14 r15
     f.sp = &s[-8];
     f.done = false;
+    f.coll = 0;
 }
 
 static void run_block(Block& b, dim3 bid) {
@@ -92,41 +95,118 @@ static void run_block(Block& b, dim3 bid) {
     g_blk = nullptr;
 }
 
+// persistent worker pool: launches are frequent and small, thread + fiber-stack creation is not
+namespace {
+struct Job {
+    dim3 grid, block;
+    size_t smem = 0;
+    const std::function<void()>* body = nullptr;
+    std::atomic<long> next{0};
+    long nblocks = 0;
+};
+
+void run_job_on_this_thread(Job& job) {
+    static thread_local Block blk;       // fibers/stacks cached per OS thread
+    Block& b = blk;
+    const int nthr = int(job.block.x * job.block.y * job.block.z);
+    if (int(b.fibers.size()) < nthr) b.fibers.resize(nthr);
+    b.n = nthr;
+    b.waves.resize((nthr + kWave - 1) / kWave);
+    b.bdim = job.block;
+    b.gdim = job.grid;
+    b.dyn_smem.resize(job.smem + 16);
+    b.body = job.body;
+    for (int t = 0; t < nthr; ++t) {
+        Fiber& f = b.fibers[t];
+        f.linear = t;
+        f.tid = dim3(t % job.block.x, (t / job.block.x) % job.block.y, t / (job.block.x * job.block.y));
+    }
+    for (;;) {
+        long i = job.next.fetch_add(1);
+        if (i >= job.nblocks) break;
+        dim3 bid(unsigned(i % job.grid.x), unsigned((i / job.grid.x) % job.grid.y),
+                 unsigned(i / (long(job.grid.x) * job.grid.y)));
+        run_block(b, bid);
+    }
+}
+
+struct Pool {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    Job* job = nullptr;
+    unsigned long epoch = 0;
+    int wanted = 0, running = 0;
+    bool stop = false;
+
+    explicit Pool(int n) {
+        for (int i = 0; i < n; ++i) threads.emplace_back([this, i] { loop(i); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> l(mu); stop = true; }
+        cv_work.notify_all();
+        for (auto& t : threads) t.join();
+    }
+    void loop(int idx) {
+        unsigned long seen = 0;
+        for (;;) {
+            Job* j;
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv_work.wait(l, [&] { return stop || (epoch != seen && idx < wanted); });
+                if (stop) return;
+                seen = epoch;
+                j = job;
+            }
+            run_job_on_this_thread(*j);
+            {
+                std::lock_guard<std::mutex> l(mu);
+                if (--running == 0) cv_done.notify_all();
+            }
+        }
+    }
+    void run(Job& j, int nworkers) {
+        std::unique_lock<std::mutex> l(mu);
+        job = &j;
+        wanted = nworkers;
+        running = nworkers;
+        ++epoch;
+        cv_work.notify_all();
+        cv_done.wait(l, [&] { return running == 0; });
+        wanted = 0;
+    }
+};
+}  // namespace
+
 void launch_impl(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
     const int nthr = int(block.x * block.y * block.z);
     const long nblocks = long(grid.x) * grid.y * grid.z;
     if (nthr <= 0 || nblocks <= 0) return;
-    int nworkers = int(std::min<long>(nblocks, std::max(1u, std::thread::hardware_concurrency())));
-    if (const char* e = getenv("HIPEMU_THREADS")) nworkers = std::max(1, std::min(nworkers, atoi(e)));
-    std::atomic<long> next{0};
-    auto worker = [&]() {
-        static thread_local Block blk;       // fibers/stacks cached per OS thread
-        Block& b = blk;
-        if (int(b.fibers.size()) < nthr) b.fibers.resize(nthr);
-        b.n = nthr;
-        b.waves.resize((nthr + kWave - 1) / kWave);
-        b.bdim = block;
-        b.gdim = grid;
-        b.dyn_smem.resize(smem + 16);
-        b.body = &body;
-        for (int t = 0; t < nthr; ++t) {
-            Fiber& f = b.fibers[t];
-            f.linear = t;
-            f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-        }
-        for (;;) {
-            long i = next.fetch_add(1);
-            if (i >= nblocks) break;
-            dim3 bid(unsigned(i % grid.x), unsigned((i / grid.x) % grid.y), unsigned(i / (long(grid.x) * grid.y)));
-            run_block(b, bid);
-        }
-    };
-    if (nworkers == 1) {
-        worker();
-    } else {
-        std::vector<std::thread> ts;
-        for (int i = 0; i < nworkers; ++i) ts.emplace_back(worker);
-        for (auto& t : ts) t.join();
+    int hw = int(std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("HIPEMU_THREADS")) hw = std::max(1, atoi(e));
+    static Pool pool(hw > 1 ? hw - 1 : 0);              // the calling thread works too
+    Job job;
+    job.grid = grid; job.block = block; job.smem = smem; job.body = &body; job.nblocks = nblocks;
+    const int helpers = int(std::min<long>(nblocks - 1, (long)pool.threads.size()));
+    if (helpers <= 0) {
+        run_job_on_this_thread(job);
+        return;
+    }
+    // helpers pull blocks from the shared counter while the caller does the same
+    std::thread* dummy = nullptr; (void)dummy;
+    {
+        std::unique_lock<std::mutex> l(pool.mu);
+        pool.job = &job;
+        pool.wanted = helpers;
+        pool.running = helpers;
+        ++pool.epoch;
+    }
+    pool.cv_work.notify_all();
+    run_job_on_this_thread(job);
+    {
+        std::unique_lock<std::mutex> l(pool.mu);
+        pool.cv_done.wait(l, [&] { return pool.running == 0; });
+        pool.wanted = 0;
     }
 }
 

@@ -58,13 +58,16 @@ struct Fiber {
     bool done = false;
     dim3 tid;
     int linear = 0;
+    unsigned coll = 0;      // number of wave collectives this lane has executed (selects the slot bank)
 };
 
 struct Wave {
     int count = 0;
     int gen = 0;
     int alive = 0;
-    alignas(16) uint32_t slot[kWave][4];
+    // two slot banks, alternated per collective: a lane can be at most one collective ahead of the
+    // slowest lane of its wave, so one rendezvous per collective is enough (write bank p, sync, read).
+    alignas(16) uint32_t slot[2][kWave][4];
 };
 
 struct Block {
@@ -140,11 +143,11 @@ inline T exchange(T v, int src_lane) {
     static_assert(sizeof(T) <= 8, "exchange width");
     Wave& w = my_wave();
     int l = lane_id();
-    std::memcpy(w.slot[l], &v, sizeof(T));
+    const unsigned bank = (cur_fiber().coll++) & 1u;
+    std::memcpy(w.slot[bank][l], &v, sizeof(T));
     sync_wave();
     T r;
-    std::memcpy(&r, w.slot[src_lane & (kWave - 1)], sizeof(T));
-    sync_wave();
+    std::memcpy(&r, w.slot[bank][src_lane & (kWave - 1)], sizeof(T));
     return r;
 }
 
@@ -220,8 +223,9 @@ typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
 static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int) {
     hipemu::Wave& w = hipemu::my_wave();
     int l = hipemu::lane_id();
-    std::memcpy(&w.slot[l][0], &a, 4);
-    std::memcpy(&w.slot[l][1], &b, 4);
+    const unsigned bank = (hipemu::cur_fiber().coll++) & 1u;
+    std::memcpy(&w.slot[bank][l][0], &a, 4);
+    std::memcpy(&w.slot[bank][l][1], &b, 4);
     hipemu::sync_wave();
     hipemu_f32x16 d = c;
     int j = l & 31;
@@ -230,13 +234,12 @@ static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float 
         float acc = c[r];
         for (int k = 0; k < 2; ++k) {
             float av, bv;
-            std::memcpy(&av, &w.slot[i + 32 * k][0], 4);
-            std::memcpy(&bv, &w.slot[j + 32 * k][1], 4);
+            std::memcpy(&av, &w.slot[bank][i + 32 * k][0], 4);
+            std::memcpy(&bv, &w.slot[bank][j + 32 * k][1], 4);
             acc = std::fmaf(av, bv, acc);
         }
         d[r] = acc;
     }
-    hipemu::sync_wave();
     return d;
 }
 
@@ -244,8 +247,9 @@ static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float 
 static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
     hipemu::Wave& w = hipemu::my_wave();
     int l = hipemu::lane_id();
-    std::memcpy(&w.slot[l][0], &a, 4);
-    std::memcpy(&w.slot[l][1], &b, 4);
+    const unsigned bank = (hipemu::cur_fiber().coll++) & 1u;
+    std::memcpy(&w.slot[bank][l][0], &a, 4);
+    std::memcpy(&w.slot[bank][l][1], &b, 4);
     hipemu::sync_wave();
     hipemu_f32x4 d = c;
     int j = l & 15;
@@ -254,13 +258,12 @@ static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b
         float acc = c[r];
         for (int k = 0; k < 4; ++k) {
             float av, bv;
-            std::memcpy(&av, &w.slot[i + 16 * k][0], 4);
-            std::memcpy(&bv, &w.slot[j + 16 * k][1], 4);
+            std::memcpy(&av, &w.slot[bank][i + 16 * k][0], 4);
+            std::memcpy(&bv, &w.slot[bank][j + 16 * k][1], 4);
             acc = std::fmaf(av, bv, acc);
         }
         d[r] = acc;
     }
-    hipemu::sync_wave();
     return d;
 }
 

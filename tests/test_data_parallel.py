@@ -1,0 +1,136 @@
+"""Multi-process data-parallel step on CPU: world_size 2 over gloo, each rank drives its own engine
+(the host-fiber emulation build of the kernels) through ``DataParallelTrainer``; the flat gradient is
+all-reduced with ``torch.distributed`` exactly as bench.py does over RCCL.
+
+Checks the semantics of SURVEY.md section 8(e): every rank ends the optimizer step with identical
+parameters, equal to a single-process reference that accumulates both ranks' micro-batches and divides
+by ``sub_batch * world``.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.common import ROOT
+
+SUB = 1
+CFG = (1, 8, 2)       # num_stack, num_fea, num_jnt  (tiny heads are fixed-width: 128/256/512)
+B = 1
+
+
+class _EmuEngine:
+    """The subset of densereg_amd.engine.Engine the trainer uses, over the emulation library."""
+
+    def __init__(self):
+        from tests.common import EmuBackend
+        from oracle.graph import NetConfig
+        self.be = EmuBackend()
+        self.cfg = NetConfig(*CFG)
+        self.h = self.be.handle(self.cfg, B, training=True)
+        addr, n = self.h.flat('grad')
+        import ctypes as C
+        self._grad = torch.from_numpy(np.ctypeslib.as_array((C.c_float * n).from_address(addr)))
+
+    def flat_view(self, which):
+        assert which == 'grad'
+        return self._grad
+
+    def load_params(self, params):
+        self.h.load_params(params)
+        self.h.call('dr_finalize_params', None)
+
+    def forward_train(self, dm, mode, keep_mask, seed):
+        import ctypes as C
+        self.h.call('dr_forward_train', dm.shape[0], dm.ctypes.data, 0, None, C.c_uint64(seed), None)
+
+    def loss(self, dm, pose, cfg, com):
+        out = np.zeros(4, np.float32)
+        self.h.call('dr_loss', dm.shape[0], dm.ctypes.data, pose.ctypes.data, cfg.ctypes.data, com.ctypes.data,
+                    out.ctypes.data, None)
+        return out
+
+    def backward(self, Bn):
+        self.h.call('dr_backward', Bn, None)
+
+    def zero_grad(self):
+        self.h.call('dr_zero_grad', None)
+
+    def apply_adam(self, lr, div, step, clip):
+        import ctypes as C
+        self.h.call('dr_apply_adam', C.c_float(lr), C.c_float(div), C.c_float(clip), C.c_int64(step), None)
+
+
+def _data(rank):
+    from densereg_amd.data.synthetic import make_crops
+    from oracle import pose
+    dm, poses, cfgs, coms, _ = make_crops(B, 'icvl', seed=300, rank=rank)
+    poses = np.ascontiguousarray(poses[:, :3 * CFG[2]])
+    return pose.norm_dm(dm, coms), poses, cfgs, coms
+
+
+def _params():
+    from oracle import net
+    from oracle.graph import NetConfig
+    return net.init_params(NetConfig(*CFG), 11)
+
+
+def _worker(rank, world, init_file, out_dir):
+    sys.path.insert(0, ROOT)
+    dist.init_process_group('gloo', init_method='file://' + init_file, rank=rank, world_size=world)
+    from densereg_amd.parallel import DataParallelTrainer
+    eng = _EmuEngine()
+    eng.load_params(_params())
+    tr = DataParallelTrainer(eng, dataset='nyu', sub_batch=SUB, dist=dist)
+    ndm, poses, cfgs, coms = _data(rank)
+    for i in range(SUB):                    # SUB micro-steps = 1 optimizer step
+        tr.micro_step(ndm, poses, cfgs, coms, seed=i, dropout_mode=0)
+    assert tr.global_step == 1
+    got = eng.h.read_params()
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), **{k.replace('/', '|'): v for k, v in got.items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_gloo_step_matches_single_process_reference():
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, 'rdzv')
+        mp.spawn(_worker, args=(world, init_file, d), nprocs=world, join=True)
+        r0 = dict(np.load(os.path.join(d, 'rank0.npz')))
+        r1 = dict(np.load(os.path.join(d, 'rank1.npz')))
+    from oracle.graph import NetConfig, trainable_names
+    names = [n.replace('/', '|') for n in trainable_names(NetConfig(*CFG))]
+    for k in names:
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)        # replicas stay in lock-step
+    # single-process reference: same engine code, both ranks' micro-batches accumulated, div = sub_batch*world
+    eng = _EmuEngine()
+    params = _params()
+    eng.load_params(params)
+    eng.zero_grad()
+    # rank-local BatchReNorm statistics: each rank's forward sees only its own crops, and its state after
+    # the first micro-step feeds its second one -- reproduce per rank on fresh engines, sum the gradients.
+    total = None
+    for rank in range(world):
+        e = _EmuEngine()
+        e.load_params(params)
+        e.zero_grad()
+        ndm, poses, cfgs, coms = _data(rank)
+        for i in range(SUB):
+            e.forward_train(ndm, 0, None, i)
+            e.loss(ndm, poses, cfgs, coms)
+            e.backward(B)
+        g = e.flat_view('grad').clone()
+        total = g if total is None else total + g
+    eng.flat_view('grad').copy_(total)
+    from densereg_amd.parallel import GRAD_CLIP, learning_rate
+    eng.apply_adam(learning_rate(0, 'nyu', B, SUB), float(SUB * world), 1, GRAD_CLIP)
+    ref = eng.h.read_params()
+    for k in names:
+        np.testing.assert_allclose(r0[k], ref[k.replace('|', '/')], rtol=1e-6, atol=1e-7, err_msg=k)
+    changed = sum(float(np.abs(r0[k] - params[k.replace('|', '/')]).max()) > 0 for k in names)
+    assert changed > len(names) * 0.9

@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--sub_batch', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--detail', default='', help='write a per-layer timing table (markdown) to this path')
     return ap.parse_args()
 
 
@@ -161,6 +162,18 @@ def main():
         nprof = max(2, min(5, args.steps))
         for i in range(nprof):
             step(1000 + i)
+        if args.detail and rank == 0:
+            rows = sorted(eng.h.profile_detail(), key=lambda r: -r['total_ms'])
+            tot = sum(r['total_ms'] for r in rows)
+            with open(args.detail, 'w') as f:
+                f.write('# per-op timing (HIP events), %s mode, B=%d, %d profiled steps\n\n' % (mode, B, nprof))
+                f.write('| op | launches/step | us/launch | ms/step | % | TFLOP/s | GB/s (algorithmic) |\n|---|---:|---:|---:|---:|---:|---:|\n')
+                for r in rows:
+                    ms = r['total_ms'] / nprof
+                    f.write('| %s | %.1f | %.1f | %.3f | %.1f | %s | %s |\n' % (
+                        r['name'], r['launches'] / nprof, r['total_ms'] * 1e3 / r['launches'], ms, 100 * r['total_ms'] / tot,
+                        ('%.1f' % (r['flops'] / (r['total_ms'] * 1e-3) / 1e12)) if r['flops'] else '-',
+                        ('%.0f' % (r['bytes'] / (r['total_ms'] * 1e-3) / 1e9)) if r['bytes'] else '-'))
         stats = eng.h.profile_read()
         eng.h.profile(False)
         convs = [s for s in stats if s['name'].startswith('conv_') and s['flops'] > 0]

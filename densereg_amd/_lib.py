@@ -61,8 +61,10 @@ SIGNATURES = {
     'dr_read_activation': (_i, [_vp, C.c_char_p, _i, _fp, _sz]),
     'dr_conv_flops_per_crop': (C.c_double, [_vp]),
     # include/densereg_debug.h (test hooks)
+    'dr_dbg_conv_bench': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
     'dr_profile_enable': (_i, [_vp, _i]),
     'dr_profile_read': (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
+    'dr_profile_detail': (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
     'dr_dbg_conv2d': (_i, [_i, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _fp, C.c_float, _fp, _i, _fp, _vp]),
 }
 
@@ -162,6 +164,13 @@ class Handle:
         arr = (KernelStat * 32)()
         n = _i()
         self.call('dr_profile_read', arr, 32, C.byref(n))
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms,
+                     flops=arr[i].flops, bytes=arr[i].bytes) for i in range(n.value)]
+
+    def profile_detail(self):
+        arr = (KernelStat * 2048)()
+        n = _i()
+        self.call('dr_profile_detail', arr, 2048, C.byref(n))
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms,
                      flops=arr[i].flops, bytes=arr[i].bytes) for i in range(n.value)]
 

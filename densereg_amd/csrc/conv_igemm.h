@@ -48,11 +48,13 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned l
     return (z >> 17) & 1ull;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK_ = 16>
 struct ConvTile {
-    static constexpr int kBK = 16;
+    static constexpr int kBK = BK_;
     static constexpr int kThreads = 256;
-    static constexpr int kSA = BM + 2;            // odd multiple of 2 mod 8: conflict-free transposing writes
+    // As row stride: the transposing ds_write_b32 of (k4, m) lane pairs is conflict-free when
+    // 4*kSA*k4 mod 32 spreads over distinct bank groups: kSA = 2 (mod 8) for BK=16, odd for BK=32
+    static constexpr int kSA = BM + (BK_ == 16 ? 2 : 1);
     static constexpr int kSB = BN;
     static constexpr int kWTM = BM / WM;          // wave tile rows
     static constexpr int kWTN = BN / WN;
@@ -66,9 +68,11 @@ struct ConvTile {
     static constexpr size_t kLdsBytes = size_t(2) * kBK * (kSA + kSB) * sizeof(float);
 };
 
-template <int BM, int BN, int WM, int WN>
+// ABL (profiling ablations, product code uses 0): 1 = no global->LDS refills after the first K-tile,
+// 2 = MFMA replaced by one VALU fma per fragment pair, 3 = no epilogue stores.
+template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
-    using T = ConvTile<BM, BN, WM, WN>;
+    using T = ConvTile<BM, BN, WM, WN, BK_>;
     constexpr int BK = T::kBK;
     constexpr int SA = T::kSA;
     constexpr int SB = T::kSB;
@@ -89,59 +93,79 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int T_total = taps * KT;
     const int pad = p.ksize / 2;
 
-    // ---- per-thread A-row bookkeeping (same rows for every K-tile) --------------------------
-    int a_row[T::kAIters];       // row inside the tile
-    int a_k4[T::kAIters];
-    int a_y[T::kAIters], a_x[T::kAIters];
-    long a_base[T::kAIters];     // element offset of (pixel m, channel 0) or -1
+    // ---- per-thread loader bookkeeping (same rows for every K-tile) ------------------------------
+    // Everything lane-dependent is computed ONCE: a 32-bit element offset, a 9-bit "tap stays inside the
+    // image" mask (TF 'SAME' zero padding + the optional depth row-mask) and the LDS coordinates.  Per
+    // K-tile only the wave-uniform part moves (tap shift and channel chunk, scalar registers), so a tile
+    // refill costs a handful of VALU ops per load instead of 64-bit address math and nested predicates.
+    int a_row[T::kAIters], a_k4[T::kAIters];
+    unsigned a_off[T::kAIters];       // element offset of (pixel m, channel 4*k4) relative to p.x
+    unsigned a_taps[T::kAIters];      // bit t: tap t reads a valid pixel for this row
 #pragma unroll
     for (int i = 0; i < T::kAIters; ++i) {
-        int idx = tid + i * T::kThreads;
-        int row = idx / (BK / 4);
+        const int idx = tid + i * T::kThreads;
+        const int row = idx / (BK / 4);
         a_row[i] = row;
         a_k4[i] = idx % (BK / 4);
-        int m = m0 + row;
+        const int m = m0 + row;
         bool ok = m < M;
         if (ok && p.rowmask) ok = !(p.rowmask[m] < p.mask_thresh);
-        int rem = ok ? (m % HW) : 0;
-        a_y[i] = rem / p.W;
-        a_x[i] = rem % p.W;
-        a_base[i] = ok ? (long)m * p.x_cs + p.x_coff : -1;
+        const int rem = ok ? (m % HW) : 0;
+        const int y = rem / p.W, x = rem % p.W;
+        unsigned mask = 0;
+        if (ok) {
+            for (int t = 0; t < taps; ++t) {
+                const int yy = y + t / p.ksize - pad, xx = x + t % p.ksize - pad;
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1u << t;
+            }
+        }
+        a_taps[i] = mask;
+        a_off[i] = ok ? (unsigned)((long)m * p.x_cs + p.x_coff + a_k4[i] * 4) : 0u;
+    }
+    unsigned b_off[T::kBIters];
+    bool b_ok[T::kBIters];
+#pragma unroll
+    for (int i = 0; i < T::kBIters; ++i) {
+        const int idx = tid + i * T::kThreads;
+        const int krow = idx / (BN / 4), n4 = idx % (BN / 4);
+        b_ok[i] = krow < BK && n0 + n4 * 4 < p.Np;
+        b_off[i] = (unsigned)(krow * p.Np + n0 + n4 * 4);
     }
 
     float4 a_reg[T::kAIters];
     float4 b_reg[T::kBIters];
 
     auto load_tile = [&](int t) {
-        const int tap = t / KT;
+        const int tap = t / KT;                               // wave-uniform
         const int kc = (t - tap * KT) * BK;
-        const int dy = tap / p.ksize - pad;
-        const int dx = tap % p.ksize - pad;
+        const int dy = tap / p.ksize - pad, dx = tap % p.ksize - pad;
+        const float* xbase = p.x + ((long)(dy * p.W + dx) * p.x_cs + kc);       // uniform: SGPR pair
+        const float* wbase = p.w + ((long)tap * p.Kp + kc) * p.Np;
+        const bool whole = kc + BK <= p.Cin;                  // uniform: no channel predicate needed
 #pragma unroll
         for (int i = 0; i < T::kAIters; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int c = kc + a_k4[i] * 4;
-            const int yy = a_y[i] + dy, xx = a_x[i] + dx;
-            if (a_base[i] >= 0 && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && c < p.Cin) {
-                const float* src = p.x + a_base[i] + (long)(dy * p.W + dx) * p.x_cs + c;
-                if (c + 4 <= p.Cin) {
+            if ((a_taps[i] >> tap) & 1u) {
+                const float* src = xbase + a_off[i];
+                if (whole) {
                     v = *reinterpret_cast<const float4*>(src);
-                } else {                       // ragged channel tail (Cin % 4 != 0)
-                    v.x = src[0];
-                    if (c + 1 < p.Cin) v.y = src[1];
-                    if (c + 2 < p.Cin) v.z = src[2];
+                } else {
+                    const int c = kc + a_k4[i] * 4;
+                    if (c + 4 <= p.Cin) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else if (c < p.Cin) {                   // ragged channel tail (Cin % 4 != 0)
+                        v.x = src[0];
+                        if (c + 1 < p.Cin) v.y = src[1];
+                        if (c + 2 < p.Cin) v.z = src[2];
+                    }
                 }
             }
             a_reg[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < T::kBIters; ++i) {
-            const int idx = tid + i * T::kThreads;
-            const int krow = idx / (BN / 4);
-            const int n4 = idx % (BN / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (krow < BK && n0 + n4 * 4 < p.Np)
-                v = *reinterpret_cast<const float4*>(p.w + ((long)tap * p.Kp + kc + krow) * p.Np + n0 + n4 * 4);
+            if (b_ok[i]) v = *reinterpret_cast<const float4*>(wbase + b_off[i]);
             b_reg[i] = v;
         }
     };
@@ -179,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int li = lane & 31;
     for (int t = 0; t < T_total; ++t) {
         const int buf = t & 1;
-        if (t + 1 < T_total) load_tile(t + 1);
+        if (ABL != 1 && t + 1 < T_total) load_tile(t + 1);
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float a[T::kTM], b[T::kTN];
@@ -190,10 +214,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int i = 0; i < T::kTM; ++i)
 #pragma unroll
-                for (int j = 0; j < T::kTN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < T::kTN; ++j) {
+                    if (ABL == 2) acc[i][j][0] = fmaf(a[i], b[j], acc[i][j][0]);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
         }
-        if (t + 1 < T_total) store_tile(buf ^ 1);
+        if (ABL != 1 && t + 1 < T_total) store_tile(buf ^ 1);
         __syncthreads();
     }
 
@@ -211,6 +237,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * T::kWTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (ABL == 3 && acc[i][j][r] != 12345.678f) continue;
                 if (m < M && n_ok && !(p.out_rowmask && p.out_rowmask[m] < p.out_mask_thresh)) {
                     const float raw = acc[i][j][r];
                     s1 += (double)raw;

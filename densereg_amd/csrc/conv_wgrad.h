@@ -147,12 +147,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
-// dst[i] += sum_s partial[s][i]
+// dst[i] += sum_s partial[s][i].  block = 64 elements x 4 split lanes, folded through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, int nsplit, long n, float* dst) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    for (long base = (long)blockIdx.x * 64; base < n; base += (long)gridDim.x * 64) {
+        const long i = base + e;
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += partial[(long)k * n + i];
-        dst[i] += s;
+        if (i < n)
+            for (int k = sl; k < nsplit; k += 4) s += partial[(long)k * n + i];
+        red[sl][e] = s;
+        __syncthreads();
+        if (sl == 0 && i < n) dst[i] += (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        __syncthreads();
     }
 }
 

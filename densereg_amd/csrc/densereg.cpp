@@ -47,11 +47,17 @@ static void launch_cfg(const ConvParams& p, hipStream_t s) {
     DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, p);
 }
 
+static int g_force_tile = -1;        // test/bench hook (dr_dbg_conv_bench); -1 = heuristic
+
 // tile shape for a problem (shared by the launcher and the profiler labels)
 int conv_tile_id(const ConvParams& p) {
     const int M = p.B * p.H * p.W;
-    if (p.Np % 128 == 0) return KID_CONV_128x128;
-    if (p.Np % 64 == 0) return ((long)dr_ceil_div(M, 128) * (p.Np / 64) >= 512) ? KID_CONV_128x64 : KID_CONV_64x64;
+    if (g_force_tile >= 0) return g_force_tile;
+    // Measured on MI355X (profiles/r01_conv_microbench.md): with M = B*H*W = 40960 rows on 256 CUs the
+    // 64-row tiles give balanced grids (1280/2560 workgroups) and beat or tie the 128-row ones on every
+    // shape of this network (3x3 256->256: 92.9 vs 83.6 TFLOP/s); 128-row tiles only pay on much deeper grids.
+    if (p.Np % 128 == 0) return ((long)dr_ceil_div(M, 128) * (p.Np / 128) >= 4096) ? KID_CONV_128x128 : KID_CONV_64x128;
+    if (p.Np % 64 == 0) return ((long)dr_ceil_div(M, 128) * (p.Np / 64) >= 4096) ? KID_CONV_128x64 : KID_CONV_64x64;
     return KID_CONV_128x32;
 }
 
@@ -59,6 +65,7 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     if (p.x_cs % 4 || p.x_coff % 4 || p.Kp % 16 || p.Np % 32) return -1;
     switch (conv_tile_id(p)) {
         case KID_CONV_128x128: launch_cfg<128, 128, 2, 2>(p, s); break;
+        case KID_CONV_64x128: launch_cfg<64, 128, 2, 2>(p, s); break;
         case KID_CONV_128x64: launch_cfg<128, 64, 2, 2>(p, s); break;
         case KID_CONV_64x64: launch_cfg<64, 64, 2, 2>(p, s); break;
         default: launch_cfg<128, 32, 4, 1>(p, s); break;
@@ -71,7 +78,7 @@ struct ProfScope {
     dr_handle* h; hipStream_t s; ProfRecord r;
     ProfScope(dr_handle* h_, hipStream_t s_, int kid, double flops, double bytes) : h(h_), s(s_) {
         if (!h->profiling) return;
-        r.kid = kid; r.flops = flops; r.bytes = bytes;
+        r.kid = kid; r.tag = h->prof_tag; r.flops = flops; r.bytes = bytes;
         r.a = rt::event_create(); r.b = rt::event_create();
         rt::event_record(r.a, s);
     }
@@ -314,7 +321,7 @@ void add_param(dr_handle* h, const std::string& name, std::initializer_list<int>
 }  // namespace
 
 static void free_all(dr_handle* h) {
-    for (void* p : {(void*)h->flat_param, (void*)h->flat_grad, (void*)h->adam_m, (void*)h->adam_v, (void*)h->flat_state,
+    for (void* p : {(void*)h->flat_param, (void*)h->flat_grad, (void*)h->adam_m, (void*)h->adam_v, (void*)h->flat_state, (void*)h->flat_state_next,
                     (void*)h->shadow, (void*)h->wp, (void*)h->wpT, (void*)h->fold, (void*)h->stats, (void*)h->bnc,
                     (void*)h->act_arena, (void*)h->grad_arena, (void*)h->scratch, (void*)h->tiny, (void*)h->tiny_ext,
                     (void*)h->losses, (void*)h->reg_segs, (void*)h->loss_acc, (void*)h->bn_coef, (void*)h->wg_partial})
@@ -420,6 +427,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         alloc_f(h->adam_m, nt);
         alloc_f(h->adam_v, nt);
         alloc_f(h->shadow, nsh);
+        alloc_f(h->flat_state_next, ns);
         alloc_f(h->wpT, nwpT);
         alloc_f(h->bnc, nbnc);
         h->stats = (double*)rt::dmalloc(std::max<size_t>(nstat, 1) * sizeof(double));
@@ -683,9 +691,11 @@ static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s
         h->fold_is_eval = true;
     }
     for (const Op& op : h->ops) {
+        h->prof_tag = op.conv;
         int rc = (op.kind == OP_CONV || op.kind == OP_STEM) ? run_conv_eval(h, op, B, s) : run_simple_op(h, op, B, s);
         if (rc) return rc;
     }
+    h->prof_tag = -1;
     DR_CHECK_LAUNCH(h);
     h->last_forward_train = false;
     h->last_B = B;
@@ -810,12 +820,98 @@ extern "C" int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, cons
     return DR_OK;
 }
 
+// Micro-benchmark of one conv shape: allocates its own buffers, `iters` launches timed with events.
+// tile: -1 heuristic, else a KernelId of a conv tile; abl: ablation variant of the 128x128 kernel.
+extern "C" int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, int tile, int abl, int iters, float* ms_out) {
+    if (!ms_out || iters < 1 || (k != 1 && k != 3)) return DR_E_INVALID;
+    const int taps = k * k, Kp = dr_round_up(Cin, 16), Np = dr_round_up(Cout, 32);
+    const int x_cs = dr_round_up(Cin, 4), y_cs = dr_round_up(Cout, 4);
+    const size_t M = (size_t)B * H * W;
+    float* x = (float*)rt::dmalloc(M * x_cs * sizeof(float));
+    float* y = (float*)rt::dmalloc(M * y_cs * sizeof(float));
+    float* wp = (float*)rt::dmalloc((size_t)taps * (Kp + 32) * Np * sizeof(float));
+    float* sc = (float*)rt::dmalloc(Np * sizeof(float));
+    if (!x || !y || !wp || !sc) return DR_E_NOMEM;
+    // deterministic non-trivial fill (bit patterns of small floats)
+    std::vector<float> hx(M * x_cs), hw((size_t)taps * (Kp + 32) * Np), hs(Np, 1.0f);
+    unsigned st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
+    for (auto& v : hx) v = rnd();
+    for (auto& v : hw) v = rnd() * 0.05f;
+    rt::h2d(x, hx.data(), hx.size() * sizeof(float), nullptr);
+    rt::h2d(wp, hw.data(), hw.size() * sizeof(float), nullptr);
+    rt::h2d(sc, hs.data(), hs.size() * sizeof(float), nullptr);
+    rt::sync_stream(nullptr);
+    ConvParams p{};
+    p.x = x; p.x_cs = x_cs; p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.ksize = k;
+    p.w = wp; p.Kp = Kp; p.Np = Np; p.y = y; p.y_cs = y_cs; p.Cout = Cout; p.scale = sc; p.shift = sc; p.relu = 1;
+    g_force_tile = tile;
+    auto launch = [&]() {
+        const int Mi = (int)M;
+        if (abl > 0) {
+            dim3 grid(dr_ceil_div(Mi, 128), dr_ceil_div(Np, 128));
+            if (abl == 4) {
+                if (Kp % 32) { p.Kp = dr_round_up(Kp, 32); }      // bench only: weights buffer is over-allocated below
+                DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 0, 32>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
+            } else if (abl == 1) DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
+            else if (abl == 2) DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
+            else DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
+        } else {
+            launch_conv_igemm(p, nullptr);
+        }
+    };
+    for (int i = 0; i < 3; ++i) launch();
+    rt::sync_stream(nullptr);
+    rt::Event a = rt::event_create(), b = rt::event_create();
+    rt::event_record(a, nullptr);
+    for (int i = 0; i < iters; ++i) launch();
+    rt::event_record(b, nullptr);
+    rt::sync_stream(nullptr);
+    *ms_out = rt::event_elapsed_ms(a, b) / iters;
+    g_force_tile = -1;
+    rt::event_destroy(a); rt::event_destroy(b);
+    rt::dfree(x); rt::dfree(y); rt::dfree(wp); rt::dfree(sc);
+    std::string m;
+    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
+}
+
 extern "C" int dr_profile_enable(dr_handle* h, int on) {
     if (!h) return DR_E_INVALID;
     rt::sync_stream(nullptr);
     for (auto& r : h->prof) { rt::event_destroy(r.a); rt::event_destroy(r.b); }
     h->prof.clear();
     h->profiling = on != 0;
+    return DR_OK;
+}
+
+// one row per (kernel, conv layer): name = "<kernel>:<scope> k<k> <cin>-><cout> @<H>"; does not reset
+extern "C" int dr_profile_detail(dr_handle* h, dr_kernel_stat* out, int max_out, int* n_out) {
+    if (!h || !out || !n_out) return DR_E_INVALID;
+    rt::sync_stream(nullptr);
+    std::map<std::pair<int, int>, dr_kernel_stat> agg;
+    for (auto& r : h->prof) {
+        auto key = std::make_pair(r.kid, r.tag);
+        auto it = agg.find(key);
+        if (it == agg.end()) {
+            dr_kernel_stat st;
+            memset(&st, 0, sizeof(st));
+            if (r.tag >= 0) {
+                const ConvLayer& c = h->convs[r.tag];
+                snprintf(st.name, sizeof(st.name), "%s:%s k%d %d->%d @%d", kKernelNames[r.kid], c.name.c_str(), c.k, c.cin, c.cout, c.H);
+            } else {
+                snprintf(st.name, sizeof(st.name), "%s", kKernelNames[r.kid]);
+            }
+            it = agg.emplace(key, st).first;
+        }
+        it->second.launches += 1;
+        it->second.total_ms += rt::event_elapsed_ms(r.a, r.b);
+        it->second.flops += r.flops;
+        it->second.bytes += r.bytes;
+    }
+    int n = 0;
+    for (auto& kv : agg)
+        if (n < max_out) out[n++] = kv.second;
+    *n_out = n;
     return DR_OK;
 }
 

@@ -78,14 +78,14 @@ struct ParamInfo {
 };
 
 enum KernelId {
-    KID_CONV_128x128, KID_CONV_128x64, KID_CONV_64x64, KID_CONV_128x32, KID_STEM, KID_POOL, KID_UPADD, KID_UVD, KID_COPY,
+    KID_CONV_128x128, KID_CONV_64x128, KID_CONV_128x64, KID_CONV_64x64, KID_CONV_128x32, KID_STEM, KID_POOL, KID_UPADD, KID_UVD, KID_COPY,
     KID_VOTE, KID_BN, KID_WGRAD, KID_ELTWISE, KID_LOSS, KID_ADAM, KID_COUNT
 };
 static const char* const kKernelNames[KID_COUNT] = {
-    "conv_igemm_128x128", "conv_igemm_128x64", "conv_igemm_64x64", "conv_igemm_128x32", "stem_conv", "maxpool",
+    "conv_igemm_128x128", "conv_igemm_64x128", "conv_igemm_128x64", "conv_igemm_64x64", "conv_igemm_128x32", "stem_conv", "maxpool",
     "upsample_add", "uvd", "copy_channels", "vote", "batch_renorm", "conv_wgrad", "eltwise_bwd", "loss", "adam"};
 
-struct ProfRecord { rt::Event a, b; int kid; double flops; double bytes; };
+struct ProfRecord { rt::Event a, b; int kid; int tag; double flops; double bytes; };
 struct RegSeg;
 
 }  // namespace dr
@@ -103,6 +103,7 @@ struct dr_handle {
     float* flat_param = nullptr; size_t n_train = 0;
     float* flat_grad = nullptr;  float* adam_m = nullptr; float* adam_v = nullptr;
     float* flat_state = nullptr; size_t n_state = 0;       // moving stats
+    float* flat_state_next = nullptr;                      // written by a training forward, then swapped in
     float* shadow = nullptr;     size_t n_shadow = 0;      // zero-debias biased accumulators
     float* wp = nullptr;         size_t n_wp = 0;          // packed forward weights
     float* wpT = nullptr;        size_t n_wpT = 0;         // packed dgrad weights
@@ -126,6 +127,7 @@ struct dr_handle {
     int dropout_mode = 0; const uint8_t* keep_mask = nullptr; uint64_t seed = 0;
     double flops_per_crop = 0.0;
     bool profiling = false;
+    int prof_tag = -1;                                     // conv index of the op being executed (profiling detail)
     std::vector<dr::ProfRecord> prof;
     // training-only state
     dr::RegSeg* reg_segs = nullptr; int n_reg = 0;        // weight segments with weight_decay > 0

@@ -13,33 +13,42 @@
 namespace dr {
 
 // ------------------------------------------------------------------------------------------------
-// BatchReNorm, train mode.  One thread per channel.
+// BatchReNorm, train mode (ops.py:130-171), fused "finalize + normalise":
 //   mean/var: biased moments of the raw conv output (fp64 sums from the conv epilogue)
 //   r = clip(std/std_mov, 1/r_max, r_max), d = clip((mean-mean_mov)/std_mov, +-d_max)   [stop-gradient]
-//   y = ((x-mean)*inv_std*r + d)*gamma + beta  ==  x*scale + shift
-//   moving stats: "read old, then update" (SURVEY Appendix C.2); assign_moving_average(decay=.99) with
-//   [TF1.3-semantics] zero_debias=True: biased -= (biased-value)*(1-decay); var = biased/(1-decay^step).
+//   out = relu(((x-mean)*inv_std*r + d)*gamma + beta) + res  ==  relu(x*scale + shift) + res
+// Every workgroup derives scale/shift of its channels from the sums (a few flops per channel);
+// workgroup 0 also persists what the backward pass and the next step need: scale|shift, bnc =
+// (mean, inv_std, r, d) and the NEW moving statistics.  Moving stats follow "read old, then update"
+// (SURVEY Appendix C.2): they are read from mm/mv and written to mm_next/mv_next (the host swaps the two
+// state buffers after the forward), so no workgroup can observe a half-updated state.
+// assign_moving_average(decay=.99) with [TF1.3-semantics] zero_debias=True:
+//   biased -= (biased-value)*(1-decay); var = biased/(1-decay^step).
+// Mapping: a thread owns 4 consecutive channels (fixed) and strides over rows: float4 traffic, no div/mod
+// in the loop, scale/shift live in registers.
 // ------------------------------------------------------------------------------------------------
-struct BnFinalizeParams {
-    const double* sum; const double* sq; double count;
+struct BnTrainParams {
+    const float* raw; int raw_cs; long M; int C;
+    const double* sum; const double* sq;
     const float* beta; const float* gamma;
-    float* mm; float* mv;             // moving mean / variance (updated in place)
+    const float* mm; const float* mv;           // moving stats BEFORE this step
+    float* mm_next; float* mv_next;             // moving stats AFTER this step
     float* shadow_mean; float* shadow_var; int shadow_step;   // step AFTER this update (>=1); 0 = plain EMA
     float r_max, d_max, eps, decay;
-    float* scale; float* shift;       // out: fused multiply-add of the normalisation
-    float* bnc;                       // out: [4][C] mean, inv_std, r, d (for the backward pass)
-    int C;
+    float* scale; float* shift;                 // persisted fused multiply-add (backward relu mask)
+    float* bnc;                                 // persisted [4][C]: mean, inv_std, r, d
+    int relu;
+    View res, out;
 };
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinalizeParams p) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= p.C) return;
-    const double mean_d = p.sum[c] / p.count;
-    double var_d = p.sq[c] / p.count - mean_d * mean_d;
+__device__ __forceinline__ void bn_channel_coeffs(const BnTrainParams& p, int c, float& sc_out, float& sh_out, bool persist) {
+    const double cnt = (double)p.M;
+    const double mean_d = p.sum[c] / cnt;
+    double var_d = p.sq[c] / cnt - mean_d * mean_d;
     if (var_d < 0.0) var_d = 0.0;
     const float mean = (float)mean_d, var = (float)var_d;
-    const float inv_std = 1.0f / sqrtf(var + p.eps);
     const float std_b = sqrtf(var + p.eps);
+    const float inv_std = 1.0f / std_b;
     const float mstd = sqrtf(p.mv[c] + p.eps);
     float r = std_b / mstd;
     r = fminf(fmaxf(r, 1.0f / p.r_max), p.r_max);
@@ -47,47 +56,71 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinalizeParams
     d = fminf(fmaxf(d, -p.d_max), p.d_max);
     const float g = p.gamma[c];
     const float sc = inv_std * r;
-    p.scale[c] = sc * g;
-    p.shift[c] = (d - mean * sc) * g + p.beta[c];
-    p.bnc[0 * p.C + c] = mean;
-    p.bnc[1 * p.C + c] = inv_std;
-    p.bnc[2 * p.C + c] = r;
-    p.bnc[3 * p.C + c] = d;
-    // moving statistics
-    const float om = 1.0f - p.decay;
-    if (p.shadow_step > 0) {
-        const float bm = p.shadow_mean[c] - (p.shadow_mean[c] - mean) * om;
-        const float bv = p.shadow_var[c] - (p.shadow_var[c] - var) * om;
-        p.shadow_mean[c] = bm;
-        p.shadow_var[c] = bv;
-        const float corr = 1.0f - powf(p.decay, (float)p.shadow_step);
-        p.mm[c] = bm / corr;
-        p.mv[c] = bv / corr;
-    } else {
-        p.mm[c] = p.mm[c] - (p.mm[c] - mean) * om;
-        p.mv[c] = p.mv[c] - (p.mv[c] - var) * om;
+    sc_out = sc * g;
+    sh_out = (d - mean * sc) * g + p.beta[c];
+    if (persist) {
+        p.scale[c] = sc_out;
+        p.shift[c] = sh_out;
+        p.bnc[0 * p.C + c] = mean;
+        p.bnc[1 * p.C + c] = inv_std;
+        p.bnc[2 * p.C + c] = r;
+        p.bnc[3 * p.C + c] = d;
+        const float om = 1.0f - p.decay;
+        if (p.shadow_step > 0) {
+            const float bm = p.shadow_mean[c] - (p.shadow_mean[c] - mean) * om;
+            const float bv = p.shadow_var[c] - (p.shadow_var[c] - var) * om;
+            p.shadow_mean[c] = bm;
+            p.shadow_var[c] = bv;
+            const float corr = 1.0f - powf(p.decay, (float)p.shadow_step);
+            p.mm_next[c] = bm / corr;
+            p.mv_next[c] = bv / corr;
+        } else {
+            p.mm_next[c] = p.mm[c] - (p.mm[c] - mean) * om;
+            p.mv_next[c] = p.mv[c] - (p.mv[c] - var) * om;
+        }
     }
 }
 
-// out(m,c) = relu(raw(m,c)*scale[c] + shift[c]) + res(m,c)        thread = (row, group of 4 channels)
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* raw, int raw_cs, const float* scale, const float* shift,
-                                                       int relu, View res, View out, long M, int C) {
-    const int c4n = (C + 3) / 4;
-    const long total = M * c4n;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c0 = int(i % c4n) * 4;
-        const long m = i / c4n;
-        const float4 x = *reinterpret_cast<const float4*>(raw + m * raw_cs + c0);
-        float v[4] = {x.x, x.y, x.z, x.w};
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams p) {
+    const int c4n = p.raw_cs / 4;                  // channel groups per row (<= 128 on this network)
+    const int rpb = 256 / c4n;                     // rows per workgroup pass
+    const int cg = threadIdx.x % c4n, rp = threadIdx.x / c4n;
+    if (rp >= rpb) return;
+    float sc[4], sh[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = c0 + k;
-            if (c < C) {
-                float y = v[k] * scale[c] + shift[c];
-                if (relu) y = fmaxf(y, 0.f);
-                if (res.p) y += res.p[m * res.cs + res.coff + c];
-                out.p[m * out.cs + out.coff + c] = y;
+    for (int k = 0; k < 4; ++k) {
+        const int c = cg * 4 + k;
+        sc[k] = 0.f; sh[k] = 0.f;
+        if (c < p.C) bn_channel_coeffs(p, c, sc[k], sh[k], blockIdx.x == 0 && rp == 0);
+    }
+    const bool full = cg * 4 + 4 <= p.C;
+    const bool vec_out = full && (p.out.coff % 4 == 0) && (p.out.cs % 4 == 0);
+    const bool vec_res = p.res.p && (p.res.coff % 4 == 0) && (p.res.cs % 4 == 0);
+    for (long m = (long)blockIdx.x * rpb + rp; m < p.M; m += (long)gridDim.x * rpb) {
+        const float4 x = *reinterpret_cast<const float4*>(p.raw + m * p.raw_cs + cg * 4);
+        float v[4] = {x.x * sc[0] + sh[0], x.y * sc[1] + sh[1], x.z * sc[2] + sh[2], x.w * sc[3] + sh[3]};
+        if (p.relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        if (p.res.p) {
+            const float* rs = p.res.p + m * p.res.cs + p.res.coff + cg * 4;
+            if (vec_res && full) {
+                const float4 rv = *reinterpret_cast<const float4*>(rs);
+                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (cg * 4 + k < p.C) v[k] += rs[k];
             }
+        }
+        float* o = p.out.p + m * p.out.cs + p.out.coff + cg * 4;
+        if (vec_out) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (cg * 4 + k < p.C) o[k] = v[k];
         }
     }
 }
@@ -97,83 +130,122 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* raw, int raw
 //   out = gamma*(r*yhat + d) + beta, yhat = (x-mean)*inv_std, g = dOut * [out_pre_relu > 0]
 //   dbeta = sum g ; dgamma = r*sum(g*yhat) + d*sum(g)
 //   dx = gamma*r*inv_std * (g - mean(g) - yhat*mean(g*yhat))
-// reduce: per-channel sum g, sum g*yhat (fp64, one atomic per block and channel)
+// reduce: per-channel sum g, sum g*yhat (fp64 partials, one atomic per workgroup and channel);
+// apply: every workgroup rebuilds the three dx coefficients from the sums, workgroup 0 also
+// accumulates dbeta/dgamma into the flat gradient.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(View dout, const float* raw, int raw_cs, const float* scale,
-                                                            const float* shift, const float* bnc, int relu, long M, int C,
-                                                            double* sum_g, double* sum_gy) {
-    __shared__ double s1[256];
-    __shared__ double s2[256];
+struct BnBwdParams {
+    View dout; const float* raw; int raw_cs; long M; int C; int relu;
+    const float* scale; const float* shift; const float* bnc; const float* gamma;
+    double* sum_g; double* sum_gy;
+    float* dbeta; float* dgamma;      // flat-gradient slices (accumulated)
+    float* draw;                      // out: gradient wrt the raw conv output, dense stride raw_cs
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p) {
+    __shared__ double s1[256 * 4];
+    __shared__ double s2[256 * 4];
+    const int c4n = p.raw_cs / 4;
+    const int rpb = 256 / c4n;
     const int tid = threadIdx.x;
-    const int cpb = C < 256 ? C : 256;
-    const int rows_par = 256 / cpb;
-    for (int c0 = 0; c0 < C; c0 += cpb) {
-        const int c = c0 + tid % cpb;
-        const int rp = tid / cpb;
-        double a = 0.0, b = 0.0;
-        if (rp < rows_par && c < C) {
-            const float sc = scale[c], sh = shift[c], mean = bnc[c], inv_std = bnc[C + c];
-            for (long m = (long)blockIdx.x * rows_par + rp; m < M; m += (long)gridDim.x * rows_par) {
-                const float x = raw[m * raw_cs + c];
-                float g = dout.p[m * dout.cs + dout.coff + c];
-                if (relu && !(x * sc + sh > 0.f)) g = 0.f;
-                const float yh = (x - mean) * inv_std;
-                a += (double)g;
-                b += (double)g * (double)yh;
+    const int cg = tid % c4n, rp = tid / c4n;
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (rp < rpb) {
+        float sc[4], sh[4], mean[4], istd[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = cg * 4 + k;
+            const bool ok = c < p.C;
+            sc[k] = ok ? p.scale[c] : 0.f; sh[k] = ok ? p.shift[c] : 0.f;
+            mean[k] = ok ? p.bnc[c] : 0.f; istd[k] = ok ? p.bnc[p.C + c] : 0.f;
+        }
+        const bool full = cg * 4 + 4 <= p.C;
+        const bool vec_d = full && (p.dout.coff % 4 == 0) && (p.dout.cs % 4 == 0);
+        for (long m = (long)blockIdx.x * rpb + rp; m < p.M; m += (long)gridDim.x * rpb) {
+            const float4 x4 = *reinterpret_cast<const float4*>(p.raw + m * p.raw_cs + cg * 4);
+            const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* dp = p.dout.p + m * p.dout.cs + p.dout.coff + cg * 4;
+            if (vec_d) {
+                const float4 d4 = *reinterpret_cast<const float4*>(dp);
+                g[0] = d4.x; g[1] = d4.y; g[2] = d4.z; g[3] = d4.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (cg * 4 + k < p.C) g[k] = dp[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (p.relu && !(x[k] * sc[k] + sh[k] > 0.f)) g[k] = 0.f;
+                const float yh = (x[k] - mean[k]) * istd[k];
+                a[k] += (double)g[k];
+                b[k] += (double)g[k] * (double)yh;
             }
         }
-        s1[tid] = a;
-        s2[tid] = b;
-        __syncthreads();
-        if (tid < cpb && c0 + tid < C) {
-            double ta = 0.0, tb = 0.0;
-            for (int r = 0; r < rows_par; ++r) { ta += s1[r * cpb + tid]; tb += s2[r * cpb + tid]; }
-            atomicAdd(&sum_g[c0 + tid], ta);
-            atomicAdd(&sum_gy[c0 + tid], tb);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s1[tid * 4 + k] = a[k]; s2[tid * 4 + k] = b[k]; }
+    __syncthreads();
+    if (tid < c4n) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = tid * 4 + k;
+            if (c < p.C) {
+                double ta = 0.0, tb = 0.0;
+                for (int r = 0; r < rpb; ++r) { ta += s1[(r * c4n + tid) * 4 + k]; tb += s2[(r * c4n + tid) * 4 + k]; }
+                atomicAdd(&p.sum_g[c], ta);
+                atomicAdd(&p.sum_gy[c], tb);
+            }
         }
-        __syncthreads();
     }
 }
 
-// per channel: parameter gradients (accumulated) and the three dx coefficients
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* sum_g, const double* sum_gy, double count,
-                                                              const float* gamma, const float* bnc, float* dbeta,
-                                                              float* dgamma, float* coef, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float sg = (float)sum_g[c], sgy = (float)sum_gy[c];
-    const float inv_std = bnc[C + c], r = bnc[2 * C + c], d = bnc[3 * C + c];
-    dbeta[c] += sg;
-    dgamma[c] += r * sgy + d * sg;
-    coef[0 * C + c] = gamma[c] * r * inv_std;
-    coef[1 * C + c] = (float)(sum_g[c] / count);
-    coef[2 * C + c] = (float)(sum_gy[c] / count);
-}
-
-// draw(m,c) = c1*(g - c2 - yhat*c3)     (draw dense, channel stride = raw_cs; pad channels zeroed)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dout, const float* raw, int raw_cs, const float* scale,
-                                                           const float* shift, const float* bnc, const float* coef, int relu,
-                                                           float* draw, long M, int C) {
-    const int c4n = raw_cs / 4;
-    const long total = M * c4n;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c0 = int(i % c4n) * 4;
-        const long m = i / c4n;
-        const float4 x4 = *reinterpret_cast<const float4*>(raw + m * raw_cs + c0);
-        const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) {
+    const int c4n = p.raw_cs / 4;
+    const int rpb = 256 / c4n;
+    const int cg = threadIdx.x % c4n, rp = threadIdx.x / c4n;
+    if (rp >= rpb) return;
+    float sc[4], sh[4], mean[4], istd[4], c1[4], c2[4], c3[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = cg * 4 + k;
+        sc[k] = sh[k] = mean[k] = istd[k] = c1[k] = c2[k] = c3[k] = 0.f;
+        if (c < p.C) {
+            sc[k] = p.scale[c]; sh[k] = p.shift[c]; mean[k] = p.bnc[c]; istd[k] = p.bnc[p.C + c];
+            const float r = p.bnc[2 * p.C + c], d = p.bnc[3 * p.C + c];
+            c1[k] = p.gamma[c] * r * istd[k];
+            c2[k] = (float)(p.sum_g[c] / (double)p.M);
+            c3[k] = (float)(p.sum_gy[c] / (double)p.M);
+            if (blockIdx.x == 0 && rp == 0) {
+                const float sg = (float)p.sum_g[c], sgy = (float)p.sum_gy[c];
+                p.dbeta[c] += sg;
+                p.dgamma[c] += r * sgy + d * sg;
+            }
+        }
+    }
+    const bool full = cg * 4 + 4 <= p.C;
+    const bool vec_d = full && (p.dout.coff % 4 == 0) && (p.dout.cs % 4 == 0);
+    for (long m = (long)blockIdx.x * rpb + rp; m < p.M; m += (long)gridDim.x * rpb) {
+        const float4 x4 = *reinterpret_cast<const float4*>(p.raw + m * p.raw_cs + cg * 4);
+        const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* dp = p.dout.p + m * p.dout.cs + p.dout.coff + cg * 4;
+        if (vec_d) {
+            const float4 d4 = *reinterpret_cast<const float4*>(dp);
+            g[0] = d4.x; g[1] = d4.y; g[2] = d4.z; g[3] = d4.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (cg * 4 + k < p.C) g[k] = dp[k];
+        }
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c = c0 + k;
-            o[k] = 0.f;
-            if (c < C) {
-                float g = dout.p[m * dout.cs + dout.coff + c];
-                if (relu && !(xv[k] * scale[c] + shift[c] > 0.f)) g = 0.f;
-                const float yh = (xv[k] - bnc[c]) * bnc[C + c];
-                o[k] = coef[c] * (g - coef[C + c] - yh * coef[2 * C + c]);
-            }
+            if (p.relu && !(x[k] * sc[k] + sh[k] > 0.f)) g[k] = 0.f;
+            const float yh = (x[k] - mean[k]) * istd[k];
+            o[k] = (cg * 4 + k < p.C) ? c1[k] * (g[k] - c2[k] - yh * c3[k]) : 0.f;
         }
-        *reinterpret_cast<float4*>(draw + m * raw_cs + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(p.draw + m * p.raw_cs + cg * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -367,7 +439,10 @@ __global__ __launch_bounds__(256) void reg_loss_kernel(const float* param, const
     __shared__ double red[4];
     const RegSeg sg = segs[blockIdx.x];
     double a = 0.0;
-    for (long i = threadIdx.x; i < sg.n; i += 256) { const double w = param[sg.off + i]; a += w * w; }
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < sg.n; i += (long)gridDim.y * 256) {
+        const double w = param[sg.off + i];
+        a += w * w;
+    }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;

@@ -16,6 +16,11 @@ int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, const float* x,
                   const float* scale, const float* shift, int relu, const float* res, int res_cs,
                   const float* rowmask, float thresh, float* y, int y_cs, double* stat, dr_stream stream);
 
+/* Micro-benchmark one conv shape on self-allocated buffers: average milliseconds per launch.
+ * tile = -1 (heuristic) or a tile id (0 128x128, 1 64x128, 2 128x64, 3 64x64, 4 128x32);
+ * abl = 0 product kernel, 1/2/3 = ablations of the 128x128 kernel (no refills / no MFMA / no stores). */
+int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, int tile, int abl, int iters, float* ms_out);
+
 /* Per-kernel timing with HIP events on the caller's stream (bench.py roofline leg).  While enabled,
  * every op of the executors is bracketed by two events; dr_profile_read synchronises, aggregates by
  * kernel, returns one row per kernel that ran, and resets.  flops/bytes are the ALGORITHMIC counts
@@ -29,6 +34,8 @@ typedef struct dr_kernel_stat {
 } dr_kernel_stat;
 int dr_profile_enable(dr_handle* h, int on);
 int dr_profile_read(dr_handle* h, dr_kernel_stat* out, int max_out, int* n_out);
+/* Same records, one row per (kernel, conv layer); call BEFORE dr_profile_read (which resets). */
+int dr_profile_detail(dr_handle* h, dr_kernel_stat* out, int max_out, int* n_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Per-shape micro-benchmark of the implicit-GEMM conv kernel (tile shapes + ablations) on an MI355X.
+
+    python tools/conv_bench.py > gpurun_out/conv_bench.md
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from densereg_amd import _lib  # noqa: E402
+
+TILES = {-1: 'auto', 0: '128x128', 1: '64x128', 2: '128x64', 3: '64x64', 4: '128x32',
+         5: 'v2 128x128', 6: 'v2 64x128', 7: 'v2 128x64', 8: 'v2 64x64', 9: 'v2 128x32'}
+ABL = {0: '', 1: 'no-refill', 2: 'no-mfma', 3: 'no-store', 4: 'BK=32', 11: 'v2 no-refill', 12: 'v2 no-mfma'}
+
+
+def main():
+    lib = _lib.load()
+    B = 40
+    shapes = [(32, 256, 256, 3), (32, 128, 128, 3), (32, 512, 512, 1), (32, 515, 512, 1), (32, 512, 256, 1),
+              (32, 256, 512, 1), (32, 256, 128, 1), (32, 128, 256, 1), (32, 128, 64, 1), (32, 64, 128, 1),
+              (32, 64, 64, 3), (32, 160, 256, 1), (32, 80, 80, 3), (16, 64, 64, 3), (16, 128, 64, 1), (8, 64, 64, 3),
+              (4, 64, 64, 3), (64, 32, 64, 1), (64, 16, 16, 3)]
+    print('| HxW | Cin | Cout | k | variant | us | TFLOP/s | % of 157.3 |')
+    print('|---:|---:|---:|---:|---|---:|---:|---:|')
+    for hw, cin, cout, k in shapes:
+        flops = 2.0 * B * hw * hw * k * k * cin * cout
+        np_ = -(-cout // 32) * 32
+        variants = [(-1, 0)]
+        if np_ % 128 == 0:
+            variants += [(0, 0), (1, 0), (5, 0), (6, 0), (0, 11), (0, 12)]
+        elif np_ % 64 == 0:
+            variants += [(2, 0), (3, 0), (7, 0), (8, 0)]
+        else:
+            variants += [(4, 0), (9, 0)]
+        for tile, abl in variants:
+            ms = C.c_float()
+            rc = lib.dr_dbg_conv_bench(B, hw, hw, cin, cout, k, tile, abl, 20, C.byref(ms))
+            if rc != 0:
+                print('| %d | %d | %d | %d | %s %s | rc=%d | | |' % (hw, cin, cout, k, TILES[tile], ABL[abl], rc))
+                continue
+            tf = flops / (ms.value * 1e-3) / 1e12
+            print('| %d | %d | %d | %d | %s %s | %.1f | %.1f | %.0f |' % (hw, cin, cout, k, TILES[tile], ABL[abl],
+                                                                      ms.value * 1e3, tf, 100 * tf / 157.3))
+        sys.stdout.flush()
+
+
+if __name__ == '__main__':
+    main()

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
     const bool full = cg * 4 + 4 <= p.C;
     const bool vec_out = full && (p.out.coff % 4 == 0) && (p.out.cs % 4 == 0);
     const bool vec_res = p.res.p && (p.res.coff % 4 == 0) && (p.res.cs % 4 == 0);
+#pragma unroll 4
     for (long m = (long)blockIdx.x * rpb + rp; m < p.M; m += (long)gridDim.x * rpb) {
         const float4 x = *reinterpret_cast<const float4*>(p.raw + m * p.raw_cs + cg * 4);
         float v[4] = {x.x * sc[0] + sh[0], x.y * sc[1] + sh[1], x.z * sc[2] + sh[2], x.w * sc[3] + sh[3]};
@@ -161,7 +162,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
         }
         const bool full = cg * 4 + 4 <= p.C;
         const bool vec_d = full && (p.dout.coff % 4 == 0) && (p.dout.cs % 4 == 0);
-        for (long m = (long)blockIdx.x * rpb + rp; m < p.M; m += (long)gridDim.x * rpb) {
+    #pragma unroll 4
+    for (long m = (long)blockIdx.x * rpb + rp; m < p.M; m += (long)gridDim.x * rpb) {
             const float4 x4 = *reinterpret_cast<const float4*>(p.raw + m * p.raw_cs + cg * 4);
             const float x[4] = {x4.x, x4.y, x4.z, x4.w};
             float g[4] = {0.f, 0.f, 0.f, 0.f};
@@ -225,6 +227,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
     }
     const bool full = cg * 4 + 4 <= p.C;
     const bool vec_d = full && (p.dout.coff % 4 == 0) && (p.dout.cs % 4 == 0);
+#pragma unroll 4
     for (long m = (long)blockIdx.x * rpb + rp; m < p.M; m += (long)gridDim.x * rpb) {
         const float4 x4 = *reinterpret_cast<const float4*>(p.raw + m * p.raw_cs + cg * 4);
         const float x[4] = {x4.x, x4.y, x4.z, x4.w};

@@ -1,0 +1,234 @@
+"""Host-side mirror of ``model/hourglass_um_crop_tiny.py`` (reference): CLI flags, ``JointDetectionModel``
+and the train / test drivers, on top of the HIP engine.
+
+    python -m densereg_amd.model.hourglass_um_crop_tiny --dataset icvl --num_stack 2 --num_fea 128 --is_train False
+    torchrun --nproc-per-node 8 -m densereg_amd.model.hourglass_um_crop_tiny --dataset msra --is_train True --num_gpus 8
+
+What maps to what
+  JointDetectionModel.test (:442-462)        -> ``test``      norm_dm + forward(eval) + vote, last stack only
+  JointDetectionModel.loss (:323-371)        -> ``loss``      targets + 3 l2 losses per stack + L2 regulariser
+  JointDetectionModel._xyz_estimation (:743) -> ``_xyz_estimation`` (the vote kernel)
+  train_single_gpu.train (:37-177)           -> ``train``     accumulate sub_batch micro-steps, clip, Adam, LR staircase
+  test_model.test (:14-94)                   -> ``test_model`` result file ``name\\t%.4f...`` with '/' -> '\\'
+The reference's datasets and checkpoints are not distributable with this repo: the drivers run on the
+seeded synthetic crop generator (``densereg_amd.data.synthetic``) and random-initialised weights unless
+``load_params`` is given real ones.  Data augmentation (``is_aug``) is a SURVEY 8(f) "next" item: accepted,
+recorded in the model name, not applied.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from datetime import datetime
+
+import numpy as np
+import torch
+
+from .. import flags
+from ..data.evaluation import Evaluation
+from ..data.synthetic import DATASETS, make_crops
+from ..network import um_v1
+from ..parallel import DataParallelTrainer, decay_steps
+
+
+class SyntheticDataset:
+    """Stand-in for data.icvl/nyu/msra: camera, joint count, sizes; batches come from make_crops."""
+
+    def __init__(self, name: str, subset: str, rank: int = 0):
+        ds = DATASETS[name]
+        self.name, self.subset, self.rank = name, subset, rank
+        self.jnt_num = ds['jnt_num']
+        self.cfg = (ds['fx'], ds['fy'], ds['cx'], ds['cy'], ds['w'], ds['h'])
+        self.approximate_num = ds['approximate_num']
+        self.exact_num = ds['exact_num']
+
+    def batch(self, batch_size: int, index: int):
+        return make_crops(batch_size, self.name, seed=flags.FLAGS.seed + 7919 * index, rank=self.rank)
+
+
+class JointDetectionModel(object):
+    _init_lr = 0.001                 # :69
+    _lr_decay_factor = 0.1           # :74
+    _adam_beta1 = 0.5                # :76
+    _input_height = _input_width = 128      # :82-83
+    _output_height = _output_width = 32     # :86-87
+    _base_dir = './exp/train_cache/'        # :92
+
+    def __init__(self, dataset, detect_net, epoch, net_desc='dummy', val_dataset=None, device: int = 0):
+        F = flags.FLAGS
+        self._dataset, self._val_dataset = dataset, val_dataset
+        self._jnt_num = int(dataset.jnt_num)
+        self._net, self._net_desc = detect_net, net_desc
+        self._num_batches_per_epoch = dataset.approximate_num / float(F.batch_size * F.sub_batch)     # :109
+        self._max_steps = int(epoch * self._num_batches_per_epoch)                                    # :112
+        self._model_desc = '%s_%s_s%d_f%d' % (dataset.name, dataset.subset, F.num_stack, F.num_fea)    # :115
+        if F.is_aug:
+            self._model_desc += '_daug'
+        self.device = torch.device('cuda', device)
+        self.engine = um_v1.get_engine(self._jnt_num, self._input_height, F.batch_size, device, bool(F.is_train))
+
+    # ---- hyper-parameters (:159-182) -----------------------------------------------------------
+    @property
+    def init_lr(self):
+        return self._init_lr
+
+    @property
+    def lr_decay_factor(self):
+        return self._lr_decay_factor
+
+    @property
+    def decay_steps(self):
+        return decay_steps(self._dataset.name, flags.FLAGS.batch_size, flags.FLAGS.sub_batch)
+
+    @property
+    def max_steps(self):
+        return self._max_steps
+
+    @property
+    def name(self):
+        return '%s_%s' % (self._model_desc, self._net_desc)              # :534-535
+
+    @property
+    def train_dir(self):
+        return os.path.join(self._base_dir, self.name)                    # :538-539
+
+    # ---- the path ---------------------------------------------------------------------------------
+    def _t(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
+
+    def inference(self, normed_dms, cfgs, coms, is_training=True):
+        return self._net(normed_dms, cfgs, coms, self._jnt_num, is_training, engine=self.engine)
+
+    def _xyz_estimation(self, hms, ums, hm3s, dms, cfgs, coms):
+        """(:743-785) -- takes the UNIT offset maps and the depth at input resolution; ``_resume_om`` (:276)
+        and ``unnorm_xyz_pose`` (:462) are inside the kernel.  Returns xyz in mm, (B, 3J)."""
+        return self.engine.vote(hms, hm3s, ums, dms, cfgs, coms)
+
+    def test(self, dms, poses, cfgs, coms):
+        """(:442-462) depth (mm) -> xyz (mm)."""
+        normed = self.engine.norm_dm(dms, coms)
+        return self.engine.infer(normed, cfgs, coms)
+
+    def loss(self, dms, poses, cfgs, coms, seed=0):
+        """(:323-371) one training micro-step's forward + loss; returns the 4 terms hm, hm3, um, reg."""
+        normed = self.engine.norm_dm(dms, coms)
+        self.engine.forward_train(normed, seed=seed)
+        return self.engine.loss(normed, poses, cfgs, coms), normed
+
+
+def result_line(name: str, xyz) -> str:
+    """test_model.py:73-76."""
+    s = '%s\t%s\n' % (name, '\t'.join(format(float(pt), '.4f') for pt in xyz))
+    return s.replace('/', '\\')
+
+
+def train(model: JointDetectionModel, dist=None, log=sys.stdout):
+    """train_single_gpu.train (:37-177) with the data-parallel reduction of SURVEY 8(e)."""
+    F = flags.FLAGS
+    trainer = DataParallelTrainer(model.engine, dataset=model._dataset.name, sub_batch=F.sub_batch, dist=dist)
+    max_steps = F.max_steps or model.max_steps
+    if log:
+        print('[train] learning rate decays per %d steps with rate=%f' % (model.decay_steps, model.lr_decay_factor), file=log)
+        print('[train] initial learning_rate = %f' % model.init_lr, file=log)
+    micro = 0
+    for step in range(max_steps):
+        start = time.time()
+        ave_loss = 0.0
+        for _ in range(F.sub_batch):
+            dm, poses, cfgs, coms, _n = model._dataset.batch(F.batch_size, micro)
+            d_dm, d_pose, d_cfg, d_com = model._t(dm), model._t(poses), model._t(cfgs), model._t(coms)
+            normed = model.engine.norm_dm(d_dm, d_com)
+            losses = trainer.micro_step(normed, d_pose, d_cfg, d_com, seed=micro)
+            loss_value = float(losses.sum().item())
+            assert not np.isnan(loss_value), 'Model diverged with loss = NaN'          # :147
+            ave_loss += loss_value
+            micro += 1
+        ave_loss /= F.sub_batch
+        duration = time.time() - start
+        if log and step % 5 == 0:
+            print('[model/train] %s: step %d/%d, loss = %.3f, %.3f sec/batch, %.3f sec/sample'
+                  % (datetime.now(), step, max_steps, ave_loss, duration, duration / (F.batch_size * F.sub_batch)), file=log)
+    return trainer
+
+
+def test_model(model: JointDetectionModel, out_path: str, log=sys.stdout):
+    """test_model.test (:14-94): run the test set, write one result line per frame, return the errors."""
+    F = flags.FLAGS
+    total = F.num_frames or model._val_dataset.exact_num
+    max_err, mean_err, n, step = [], [], 0, 0
+    with open(out_path, 'w') as f:
+        while n < total:
+            dm, poses, cfgs, coms, names = model._val_dataset.batch(F.batch_size, step)
+            xyz = model.test(model._t(dm), model._t(poses), model._t(cfgs), model._t(coms)).cpu().numpy()
+            for xyz_val, gt_val, name in zip(xyz, poses, names):
+                max_err.append(Evaluation.maxJntError(xyz_val, gt_val))
+                mean_err.append(Evaluation.meanJntError(xyz_val, gt_val))
+                f.write(result_line(name, xyz_val))
+                n += 1
+                if n >= total:
+                    break
+            step += 1
+    Evaluation.plotError(max_err, out_path.replace('.txt', '') + '_error.txt')
+    if log:
+        print('finish test: %d frames, mean joint error %.3f mm (random weights unless parameters were loaded)'
+              % (n, float(np.mean(mean_err))), file=log)
+    return max_err, mean_err
+
+
+def run_train(dataset, val_dataset, dist=None, device=0):
+    net_module = __import__('densereg_amd.network.' + flags.FLAGS.net_module, fromlist=['detect_net'])      # :863-867
+    model = JointDetectionModel(dataset, net_module.detect_net, epoch=flags.FLAGS.epoch, net_desc=net_module.TOWER_NAME,
+                                val_dataset=val_dataset, device=device)
+    return model, train(model, dist)
+
+
+def run_test(train_dataset, test_dataset, out_path=None, device=0):
+    net_module = __import__('densereg_amd.network.' + flags.FLAGS.net_module, fromlist=['detect_net'])      # :874-878
+    model = JointDetectionModel(train_dataset, net_module.detect_net, epoch=flags.FLAGS.epoch, net_desc=net_module.TOWER_NAME,
+                                val_dataset=test_dataset, device=device)
+    os.makedirs(model.train_dir, exist_ok=True)
+    out_path = out_path or os.path.join(model.train_dir, '%s-%s-result.txt' % (test_dataset.subset, datetime.now().strftime('%Y-%m-%d_%H:%M:%S')))
+    return model, test_model(model, out_path), out_path
+
+
+def _random_params(engine, seed=7):
+    rng = np.random.default_rng(seed)
+    params = {}
+    for name, shape, _ in engine.param_infos():
+        leaf = name.rsplit('/', 1)[1]
+        if leaf == 'weights':
+            params[name] = np.clip(rng.standard_normal(shape), -2, 2).astype(np.float32) * 0.01      # ops.py:272 trunc-normal 0.01
+        elif leaf in ('gamma', 'moving_variance', 'r_max'):
+            params[name] = np.ones(shape, np.float32)
+        else:
+            params[name] = np.zeros(shape, np.float32)
+    return params
+
+
+def main(argv=None):
+    F = flags.parse(argv)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dataset = SyntheticDataset(F.dataset, 'training', rank)
+    val_dataset = SyntheticDataset(F.dataset, 'testing', rank)
+    eng = um_v1.get_engine(dataset.jnt_num, 128, F.batch_size, local, bool(F.is_train))
+    eng.load_params(_random_params(eng))
+    if F.is_train:
+        run_train(dataset, val_dataset, dist, local)
+    else:
+        _, (max_err, mean_err), out = run_test(dataset, val_dataset, device=local)
+        print('results written to %s' % out)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

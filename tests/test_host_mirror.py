@@ -1,0 +1,94 @@
+"""Host-side mirror of the reference's CLI / model interface / result-file format (CPU tests + one GPU run)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from tests.common import GOLDEN
+
+
+def test_flags_match_reference_names_and_defaults():
+    from densereg_amd import flags
+    F = flags.parse([])
+    # model/hourglass_um_crop_tiny.py:29-60
+    assert (F.num_gpus, F.batch_size, F.debug_level, F.sub_batch, F.pid) == (1, 40, 1, 5, 0)
+    assert (F.is_train, F.net_module, F.is_aug, F.dataset, F.epoch) == (True, 'um_v1', True, 'nyu', 80)
+    assert (F.num_stack, F.num_fea, F.kernel_size) == (2, 128, 3)
+    F = flags.parse(['--dataset', 'icvl', '--fea_num', '64', '--num_stack', '1', '--is_train', 'False', '--batch_size', '8'])
+    assert F.num_fea == 64 and F.num_stack == 1 and F.is_train is False and F.dataset == 'icvl'      # README spelling accepted
+    F = flags.parse(['--num_fea', '256', '--is_train', 'True'])
+    assert F.num_fea == 256 and F.is_train is True
+    flags.parse([])
+
+
+def test_result_line_format_matches_shipped_prediction_files():
+    """exp/result/icvl.txt / nyu.txt pin the output FORMAT: name, tab, %.4f fields, '\\' separators."""
+    from densereg_amd.model.hourglass_um_crop_tiny import result_line
+    for fname, J in (('icvl_result_head.txt', 16), ('nyu_result_head.txt', 14)):
+        for line in open(os.path.join(GOLDEN, fname)):
+            fields = line.rstrip('\n').split('\t')
+            assert len(fields) == 1 + 3 * J
+            vals = np.array([float(v) for v in fields[1:]])
+            name_fwd = fields[0].replace('\\', '/')                  # what the dataset reader would hand over
+            assert result_line(name_fwd, vals) == line              # byte-identical re-serialisation
+    assert result_line('a/b.png', [1, 2.00004, -3.5]) == 'a\\b.png\t1.0000\t2.0000\t-3.5000\n'
+
+
+def test_lr_schedule_and_model_naming():
+    from densereg_amd import flags
+    from densereg_amd.parallel import decay_steps, learning_rate
+    # hourglass_um_crop_tiny.py:109,174 + train_single_gpu.py:45-49: nyu: 73730/(40*5)*10 = 3686.5 steps
+    assert abs(decay_steps('nyu', 40, 5) - 3686.5) < 1e-9
+    assert abs(decay_steps('msra', 40, 5) - 68085 / 200.0 * 20) < 1e-9
+    assert learning_rate(0, 'nyu', 40, 5) == 1e-3 and learning_rate(3686, 'nyu', 40, 5) == 1e-3
+    assert math.isclose(learning_rate(3687, 'nyu', 40, 5), 1e-4) and math.isclose(learning_rate(7373, 'nyu', 40, 5), 1e-5)
+    flags.parse([])
+
+
+def test_evaluation_metrics_and_curve(tmp_path):
+    from densereg_amd.data.evaluation import Evaluation
+    a, b = np.zeros(6), np.array([3, 4, 0, 0, 0, 12.0])
+    assert Evaluation.maxJntError(a, b) == 12.0 and Evaluation.meanJntError(a, b) == 8.5     # evaluation.py:9-18
+    th, frac = Evaluation.plotError([1.0, 5.0, 50.0], str(tmp_path / 'e.txt'))
+    assert frac[0] == 0 and abs(frac[10] - 2 / 3) < 1e-9 and frac[-1] == 1.0
+
+
+def test_synthetic_dataset_constants():
+    from densereg_amd.data.synthetic import DATASETS, make_crops
+    assert [DATASETS[k]['jnt_num'] for k in ('icvl', 'nyu', 'msra')] == [16, 14, 21]          # icvl.py:17, nyu.py:40-45, msra.py:17
+    assert DATASETS['icvl']['exact_num'] == 1596 and DATASETS['nyu']['exact_num'] == 8252
+    dm, pose, cfg, com, names = make_crops(3, 'nyu', seed=1)
+    dm2 = make_crops(3, 'nyu', seed=1)[0]
+    np.testing.assert_array_equal(dm, dm2)
+    assert dm.shape == (3, 128, 128, 1) and pose.shape == (3, 42) and cfg.shape == (3, 6) and com.shape == (3, 3)
+    assert 0.25 < (dm > 0).mean() < 0.6 and np.all(cfg[:, 4:] == 128)
+
+
+@pytest.mark.gpu
+def test_cli_test_and_train_drivers_on_gpu(gpu, tmp_path, monkeypatch):
+    from densereg_amd import flags
+    from densereg_amd.model import hourglass_um_crop_tiny as M
+    monkeypatch.chdir(tmp_path)
+    flags.parse(['--dataset', 'icvl', '--num_stack', '1', '--fea_num', '64', '--is_train', 'False', '--batch_size', '8',
+                 '--num_frames', '20'])
+    ds, vs = M.SyntheticDataset('icvl', 'training'), M.SyntheticDataset('icvl', 'testing')
+    from densereg_amd.network import um_v1
+    eng = um_v1.get_engine(16, 128, 8, 0, False)
+    eng.load_params(M._random_params(eng))
+    model, (max_err, mean_err), out = M.run_test(ds, vs)
+    lines = open(out).read().splitlines()
+    assert len(lines) == 20 and all(len(l.split('\t')) == 49 for l in lines) and '\\' in lines[0] and '/' not in lines[0]
+    assert model.name == 'icvl_training_s1_f64_daug_um_v1'            # hourglass_um_crop_tiny.py:115-117,534-535
+    # two optimizer steps of the training driver
+    flags.parse(['--dataset', 'nyu', '--num_stack', '1', '--fea_num', '64', '--is_train', 'True', '--batch_size', '4',
+                 '--sub_batch', '2', '--max_steps', '2'])
+    ds = M.SyntheticDataset('nyu', 'training')
+    eng = um_v1.get_engine(14, 128, 4, 0, True)
+    eng.load_params(M._random_params(eng))
+    before = eng.read_params()
+    model, trainer = M.run_train(ds, None)
+    after = eng.read_params()
+    assert trainer.global_step == 2
+    assert any(np.abs(after[k] - before[k]).max() > 0 for k in before if k.endswith('weights'))
+    flags.parse([])

@@ -10,9 +10,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from densereg_amd import _lib  # noqa: E402
 
-TILES = {-1: 'auto', 0: '128x128', 1: '64x128', 2: '128x64', 3: '64x64', 4: '128x32',
-         5: 'v2 128x128', 6: 'v2 64x128', 7: 'v2 128x64', 8: 'v2 64x64', 9: 'v2 128x32'}
-ABL = {0: '', 1: 'no-refill', 2: 'no-mfma', 3: 'no-store', 4: 'BK=32', 11: 'v2 no-refill', 12: 'v2 no-mfma'}
+TILES = {-1: 'auto', 0: '128x128', 1: '64x128', 2: '128x64', 3: '64x64', 4: '128x32'}
+ABL = {0: '', 1: 'no-refill', 2: 'no-mfma', 3: 'no-store', 4: 'BK=32'}
 
 
 def main():
@@ -29,11 +28,9 @@ def main():
         np_ = -(-cout // 32) * 32
         variants = [(-1, 0)]
         if np_ % 128 == 0:
-            variants += [(0, 0), (1, 0), (5, 0), (6, 0), (0, 11), (0, 12)]
+            variants += [(0, 0), (1, 0), (0, 1), (0, 2)]
         elif np_ % 64 == 0:
-            variants += [(2, 0), (3, 0), (7, 0), (8, 0)]
-        else:
-            variants += [(4, 0), (9, 0)]
+            variants += [(2, 0), (3, 0)]
         for tile, abl in variants:
             ms = C.c_float()
             rc = lib.dr_dbg_conv_bench(B, hw, hw, cin, cout, k, tile, abl, 20, C.byref(ms))

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; ROCm 7.2 rocpd DBs).
+
+    python tools/rocpd_pmc.py gpurun_out/pmc_fetch/fetch_results.db gpurun_out/pmc_write/write_results.db
+
+Unit handling as MI355X_MICROARCH.md "HBM" prescribes: counters are kilobytes; on gfx950 FETCH_SIZE
+reports exactly half the bytes of a wide coalesced streaming read (128-B requests tallied as 64 B), so it is
+doubled; WRITE_SIZE is uncalibrated and taken as reported.
+"""
+import sqlite3
+import sys
+
+
+def per_kernel(path, counter):
+    db = sqlite3.connect(path)
+    rows = db.execute('select kernel_name, count(*), sum(value), sum(duration) from counters_collection '
+                      'where counter_name=? group by kernel_name', (counter,)).fetchall()
+    return {r[0]: (r[1], r[2], r[3]) for r in rows}
+
+
+def main(fetch_db, write_db):
+    f = per_kernel(fetch_db, 'FETCH_SIZE')
+    w = per_kernel(write_db, 'WRITE_SIZE')
+    names = sorted(set(f) | set(w), key=lambda n: -(2 * f.get(n, (0, 0, 0))[1] + w.get(n, (0, 0, 0))[1]))
+    print('# HBM traffic per kernel from PMC passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE as reported)')
+    print()
+    print('| kernel | launches | read MB/launch (corrected) | write MB/launch | total GB (all launches) |')
+    print('|---|---:|---:|---:|---:|')
+    for n in names:
+        nf, kb_f, _ = f.get(n, (0, 0.0, 0))
+        nw, kb_w, _ = w.get(n, (0, 0.0, 0))
+        launches = max(nf, nw, 1)
+        rd = 2.0 * kb_f * 1024 / launches / 1e6
+        wr = kb_w * 1024 / max(nw, 1) / 1e6
+        short = n if len(n) < 90 else n[:87] + '...'
+        print('| `%s` | %d | %.2f | %.2f | %.2f |' % (short, launches, rd, wr, (2.0 * kb_f + kb_w) * 1024 / 1e9))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])

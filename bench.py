@@ -86,6 +86,17 @@ def cpu_baseline(mode, cfg_tuple, B, dataset):
                       % (len(times), Bc, 'fwd(eval)+vote' if mode == 'infer' else 'fwd+bwd', ncores, avail)}
 
 
+def pmc_traffic(mode, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/rocpd_pmc.py --json; rocprofv3
+    cannot collect counters from inside this process).  None when no measurement of this mode/kernel exists."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        e = json.load(open(path))[mode][kernel]
+        return e['read_bytes_per_launch'] + e['write_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -181,7 +192,7 @@ def main():
             dom = max(convs, key=lambda s: s['total_ms'])
             ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
             roof = {'kernel': dom['name'], 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                    'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(mode, dom['name']),
                     'launches_per_step': dom['launches'] / nprof, 'avg_launch_us': dom['total_ms'] * 1e3 / dom['launches'],
                     'algorithmic_gflop_per_launch': dom['flops'] / dom['launches'] / 1e9,
                     'share_of_step_time': dom['total_ms'] / max(sum(s['total_ms'] for s in stats), 1e-9),

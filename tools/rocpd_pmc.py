@@ -36,5 +36,40 @@ def main(fetch_db, write_db):
         print('| `%s` | %d | %.2f | %.2f | %.2f |' % (short, launches, rd, wr, (2.0 * kb_f + kb_w) * 1024 / 1e9))
 
 
+def short_name(n):
+    import re
+    m = re.search(r'conv_igemm_kernel<(\d+), (\d+)', n)
+    if m:
+        return 'conv_igemm_%sx%s' % (m.group(1), m.group(2))
+    if 'conv_wgrad_kernel' in n:
+        return 'conv_wgrad'
+    return None
+
+
+def to_json(fetch_db, write_db, mode, out_path):
+    import json
+    import os
+    f = per_kernel(fetch_db, 'FETCH_SIZE')
+    w = per_kernel(write_db, 'WRITE_SIZE')
+    agg = {}
+    for n in set(f) | set(w):
+        k = short_name(n)
+        if not k:
+            continue
+        a = agg.setdefault(k, [0, 0.0, 0, 0.0])
+        nf, kb_f, _ = f.get(n, (0, 0.0, 0))
+        nw, kb_w, _ = w.get(n, (0, 0.0, 0))
+        a[0] += nf; a[1] += kb_f; a[2] += nw; a[3] += kb_w
+    data = json.load(open(out_path)) if os.path.exists(out_path) else {}
+    data[mode] = {k: {'read_bytes_per_launch': 2.0 * v[1] * 1024 / max(v[0], 1), 'write_bytes_per_launch': v[3] * 1024 / max(v[2], 1),
+                      'launches_sampled': v[0],
+                      'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950), KB -> bytes'}
+                  for k, v in agg.items()}
+    json.dump(data, open(out_path, 'w'), indent=1, sort_keys=True)
+
+
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    if len(sys.argv) >= 6 and sys.argv[3] == '--json':
+        to_json(sys.argv[1], sys.argv[2], sys.argv[4], sys.argv[5])
+    else:
+        main(sys.argv[1], sys.argv[2])

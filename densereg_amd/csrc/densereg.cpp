@@ -58,6 +58,7 @@ int conv_tile_id(const ConvParams& p) {
     // shape of this network (3x3 256->256: 92.9 vs 83.6 TFLOP/s); 128-row tiles only pay on much deeper grids.
     if (p.Np % 128 == 0) return ((long)dr_ceil_div(M, 128) * (p.Np / 128) >= 4096) ? KID_CONV_128x128 : KID_CONV_64x128;
     if (p.Np % 64 == 0) return ((long)dr_ceil_div(M, 128) * (p.Np / 64) >= 4096) ? KID_CONV_128x64 : KID_CONV_64x64;
+    if (p.Np == 96) return KID_CONV_128x96;          // 65/78/80-wide layers: one N block, the A tile is read once
     return KID_CONV_128x32;
 }
 
@@ -68,6 +69,7 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         case KID_CONV_64x128: launch_cfg<64, 128, 2, 2>(p, s); break;
         case KID_CONV_128x64: launch_cfg<128, 64, 2, 2>(p, s); break;
         case KID_CONV_64x64: launch_cfg<64, 64, 2, 2>(p, s); break;
+        case KID_CONV_128x96: launch_cfg<128, 96, 4, 1>(p, s); break;
         default: launch_cfg<128, 32, 4, 1>(p, s); break;
     }
     return 0;

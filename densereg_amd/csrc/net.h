@@ -17,6 +17,7 @@ struct Tensor {
     float* p = nullptr;                // forward values   [max_batch*H*W*cs]
     float* g = nullptr;                // gradient buffer (training handles)
     bool needs_grad = true;
+    bool needs_zero = false;           // gradient buffer must be zeroed before a backward pass (see plan_backward)
     std::string tag;
 };
 
@@ -63,6 +64,7 @@ struct Op {
     int dropout = -1;                  // dropout slot index (stack*2 + i) or -1
     int pool_k = 0;
     TView uvd0, uvd1;                  // OP_UVD destinations
+    bool ow_in = false, ow_in2 = false; // backward: this op is the FIRST writer of grad(in) / grad(in2) -> overwrite
 };
 
 enum ParamKind { PK_WEIGHT, PK_BETA, PK_GAMMA, PK_BIAS, PK_MMEAN, PK_MVAR, PK_RMAX, PK_DMAX, PK_CURRT };
@@ -78,11 +80,11 @@ struct ParamInfo {
 };
 
 enum KernelId {
-    KID_CONV_128x128, KID_CONV_64x128, KID_CONV_128x64, KID_CONV_64x64, KID_CONV_128x32, KID_STEM, KID_POOL, KID_UPADD, KID_UVD, KID_COPY,
+    KID_CONV_128x128, KID_CONV_64x128, KID_CONV_128x64, KID_CONV_64x64, KID_CONV_128x32, KID_CONV_128x96, KID_STEM, KID_POOL, KID_UPADD, KID_UVD, KID_COPY,
     KID_VOTE, KID_BN, KID_WGRAD, KID_ELTWISE, KID_LOSS, KID_ADAM, KID_COUNT
 };
 static const char* const kKernelNames[KID_COUNT] = {
-    "conv_igemm_128x128", "conv_igemm_64x128", "conv_igemm_128x64", "conv_igemm_64x64", "conv_igemm_128x32", "stem_conv", "maxpool",
+    "conv_igemm_128x128", "conv_igemm_64x128", "conv_igemm_128x64", "conv_igemm_64x64", "conv_igemm_128x32", "conv_igemm_128x96", "stem_conv", "maxpool",
     "upsample_add", "uvd", "copy_channels", "vote", "batch_renorm", "conv_wgrad", "eltwise_bwd", "loss", "adam"};
 
 struct ProfRecord { rt::Event a, b; int kid; int tag; double flops; double bytes; };

@@ -329,8 +329,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* x, int x_
     }
 }
 
-// upsample-add backward: da += dout ; dlo(y/2,x/2) += sum of the 2x2 block of dout.  thread = (lo pixel, channel)
-__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(View dout, View da, View dlo, int B, int H, int W, int C) {
+// upsample-add backward: da (+)= dout ; dlo(y/2,x/2) (+)= sum of the 2x2 block of dout.  thread = (lo pixel, channel)
+// acc_a / acc_lo = 0: this is the first gradient written into that buffer (overwrite, buffer not zeroed).
+__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(View dout, View da, View dlo, int B, int H, int W, int C,
+                                                               int acc_a, int acc_lo) {
     const int h2 = H / 2, w2 = W / 2;
     const long total = (long)B * h2 * w2 * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -346,10 +348,12 @@ __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(View dout, View d
             for (int dx = 0; dx < 2; ++dx) {
                 const long pix = ((long)b * H + ly * 2 + dy) * W + lx * 2 + dx;
                 const float g = dout.p[pix * dout.cs + dout.coff + c];
-                da.p[pix * da.cs + da.coff + c] += g;
+                float* q = da.p + pix * da.cs + da.coff + c;
+                *q = acc_a ? (*q + g) : g;
                 s += g;
             }
-        dlo.p[lp * dlo.cs + dlo.coff + c] += s;
+        float* q = dlo.p + lp * dlo.cs + dlo.coff + c;
+        *q = acc_lo ? (*q + s) : s;
     }
 }
 

@@ -75,6 +75,15 @@ def _run_step(be, cfg, params, ndm, poses, cfgs, coms, masks):
           % (e_eng.max(), np.median(e_eng), e_o32.max(), np.median(e_o32)))
     assert e_eng.max() < 6e-2 and np.median(e_eng) < 1e-2
     assert np.median(e_eng) < 2 * np.median(e_o32) + 1e-4
+    # a second loss+backward on the same forward must add exactly the same gradient again: catches gradient
+    # buffers that are neither zeroed nor overwritten by their first writer (train_exec.inc plan_backward)
+    h.call('dr_loss', B, be.ptr(d_dm), be.ptr(d_pose), be.ptr(d_cfg), be.ptr(d_com), be.ptr(d_lo), be.stream)
+    h.call('dr_backward', B, be.stream)
+    be.sync()
+    g2 = flat_grads_by_name(be, h, cfg)
+    for name in g:
+        sc = np.abs(g[name]).max() + 1e-12
+        assert np.abs(g2[name] - 2.0 * g[name]).max() / sc < 1e-4, name
     # BatchReNorm state after one micro-step (moving stats with zero-debias, r_max/d_max/curr_t schedule)
     p2 = {k: v.copy() for k, v in params.items()}
     net.bn_state_update(p2, upd, zero_debias=True, shadow={})

@@ -58,7 +58,6 @@ int conv_tile_id(const ConvParams& p) {
     // shape of this network (3x3 256->256: 92.9 vs 83.6 TFLOP/s); 128-row tiles only pay on much deeper grids.
     if (p.Np % 128 == 0) return ((long)dr_ceil_div(M, 128) * (p.Np / 128) >= 4096) ? KID_CONV_128x128 : KID_CONV_64x128;
     if (p.Np % 64 == 0) return ((long)dr_ceil_div(M, 128) * (p.Np / 64) >= 4096) ? KID_CONV_128x64 : KID_CONV_64x64;
-    if (p.Np == 96) return KID_CONV_128x96;          // 65/78/80-wide layers: one N block, the A tile is read once
     return KID_CONV_128x32;
 }
 

@@ -103,9 +103,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('DR_FORCE_ALLREDUCE') == '1':
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world)
     assert world == args.gpus or world == 1, 'launch N>1 through torch.distributed.run'
     torch.cuda.set_device(local)

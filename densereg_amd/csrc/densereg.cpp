@@ -30,6 +30,10 @@ static std::string g_create_err;
         if (rt::last_error(&_m)) DR_FAIL(h, DR_E_DEVICE, "HIP error: %s (%s:%d)", _m.c_str(), __FILE__, __LINE__); \
     } while (0)
 
+// every entry point re-selects the handle's device: the HIP current device is per host thread and the caller
+// (PyTorch) may have moved it
+#define DR_ENTER(h) (void)rt::set_device((h)->cfg.device)
+
 static inline int grid_for(long total, int block = 256, int cap = 256 * 8) {
     long g = (total + block - 1) / block;
     return (int)std::max<long>(1, std::min<long>(g, cap));
@@ -69,6 +73,13 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         case KID_CONV_128x64: launch_cfg<128, 64, 2, 2>(p, s); break;
         case KID_CONV_64x64: launch_cfg<64, 64, 2, 2>(p, s); break;
         case KID_CONV_128x96: launch_cfg<128, 96, 4, 1>(p, s); break;
+        case KID_CONV_64x128_K32: {
+            if (p.Kp % 32) return -1;
+            const int M = p.B * p.H * p.W;
+            dim3 grid(dr_ceil_div(M, 64), dr_ceil_div(p.Np, 128));
+            DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 0, 32>), grid, dim3(256), 0, s, p);
+            break;
+        }
         default: launch_cfg<128, 32, 4, 1>(p, s); break;
     }
     return 0;
@@ -582,6 +593,7 @@ static int fold_bn(dr_handle* h, hipStream_t s) {
 
 int dr_finalize_params(dr_handle* h, dr_stream stream) {
     if (!h) return DR_E_INVALID;
+    DR_ENTER(h);
     hipStream_t s = (hipStream_t)stream;
     int rc = repack_weights(h, s);
     if (rc) return rc;
@@ -597,6 +609,7 @@ int dr_finalize_params(dr_handle* h, dr_stream stream) {
 int dr_norm_dm(dr_handle* h, int B, const float* dm, const float* com, float* out, dr_stream stream) {
     if (!h || !dm || !com || !out) return DR_E_INVALID;
     if (B < 1) DR_FAIL(h, DR_E_INVALID, "dr_norm_dm: B=%d", B);
+    DR_ENTER(h);
     const int npix = h->cfg.in_hw * h->cfg.in_hw;
     DR_LAUNCH(norm_dm_kernel, dim3(grid_for((long)B * npix)), dim3(256), 0, (hipStream_t)stream, dm, com, out, B, npix);
     DR_CHECK_LAUNCH(h);
@@ -685,6 +698,7 @@ static int run_simple_op(dr_handle* h, const Op& op, int B, hipStream_t s) {
 static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s) {
     if (!h->finalized) DR_FAIL(h, DR_E_STATE, "forward before dr_finalize_params");
     if (B < 1 || B > h->cfg.max_batch) DR_FAIL(h, DR_E_INVALID, "batch %d outside [1, max_batch=%d]", B, h->cfg.max_batch);
+    DR_ENTER(h);
     h->dm_in = dm;
     if (!h->fold_is_eval) {          // a training forward overwrote the per-layer scale/shift
         int rc = fold_bn(h, s);
@@ -750,6 +764,7 @@ int dr_vote(dr_handle* h, int B, const float* hm, const float* hm3, const float*
             const float* com, float* xyz, dr_stream stream) {
     if (!h || !hm || !hm3 || !um || !dm || !cfg || !com || !xyz) return DR_E_INVALID;
     if (B < 1 || B > h->cfg.max_batch) DR_FAIL(h, DR_E_INVALID, "batch %d outside [1, max_batch=%d]", B, h->cfg.max_batch);
+    DR_ENTER(h);
     hipStream_t s = (hipStream_t)stream;
     const int J = h->cfg.num_jnt, mh = h->map_hw;
     DR_LAUNCH(uvd_kernel, dim3(grid_for((long)B * mh * mh)), dim3(256), 0, s, dm, B, h->cfg.in_hw, h->tiny_ext, (float*)nullptr,
@@ -874,6 +889,13 @@ extern "C" int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, 
     rt::dfree(x); rt::dfree(y); rt::dfree(wp); rt::dfree(sc);
     std::string m;
     return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
+}
+
+// force the conv tile choice of every following launch (-1 = heuristic); tests sweep all tile shapes with it
+extern "C" int dr_dbg_force_tile(int tile) {
+    if (tile < -1 || tile > KID_CONV_64x128_K32) return DR_E_INVALID;
+    g_force_tile = tile;
+    return DR_OK;
 }
 
 extern "C" int dr_profile_enable(dr_handle* h, int on) {

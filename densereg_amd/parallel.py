@@ -12,6 +12,7 @@ there is no other data-path collective; moving BatchReNorm statistics stay per-r
 from __future__ import annotations
 
 import math
+import os
 
 from .data.synthetic import DATASETS
 
@@ -46,7 +47,7 @@ class DataParallelTrainer:
             engine.zero_grad()
 
     def reduce_gradients(self):
-        if self.world > 1:
+        if self.world > 1 or (self.dist is not None and os.environ.get('DR_FORCE_ALLREDUCE') == '1'):
             if self._all_reduce is not None:
                 self._all_reduce(self.flat_grad)
             else:

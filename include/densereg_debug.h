@@ -21,6 +21,10 @@ int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, const float* x,
  * abl = 0 product kernel, 1/2/3 = ablations of the 128x128 kernel (no refills / no MFMA / no stores). */
 int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, int tile, int abl, int iters, float* ms_out);
 
+/* Force the conv tile of every following launch (-1 = heuristic; ids as in dr_dbg_conv_bench, 5 = 128x96,
+ * 6 = 64x128 with BK=32).  Process-global; tests use it to check every tile shape against the reference. */
+int dr_dbg_force_tile(int tile);
+
 /* Per-kernel timing with HIP events on the caller's stream (bench.py roofline leg).  While enabled,
  * every op of the executors is bracketed by two events; dr_profile_read synchronises, aggregates by
  * kernel, returns one row per kernel that ran, and resets.  flops/bytes are the ALGORITHMIC counts

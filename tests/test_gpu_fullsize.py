@@ -96,3 +96,27 @@ def test_every_layer_config2_small_batch(gpu, config2):
         a = gpu.read_activation(c['h'], cs.name, (2, cs.h_out, cs.w_out, cs.cout))
         r = rec.get(cs.name + '+res', rec[cs.name])
         assert np.abs(a - r).max() / (np.abs(r).max() + 1e-12) < 2e-4, cs.name
+
+
+def test_input_256_maps_64_forward_and_vote(gpu):
+    """um_v1.py:99-104 accepts 256x256 crops (hourglass depth 5, 64x64 maps): BASELINE config 5's geometry
+    (fp32 here), S=1 F=64 J=14 B=2 against the oracle."""
+    from densereg_amd.data.synthetic import make_crops
+    from oracle import net, pose
+    from oracle.graph import NetConfig
+    cfg = NetConfig(1, 64, 14, in_hw=256)
+    dm, poses, cfgs, coms, _ = make_crops(2, 'nyu', seed=3, hw=256)
+    ndm = pose.norm_dm(dm, coms)
+    params = net.make_test_params(cfg, ndm, seed=7)
+    h = gpu.handle(cfg, 2)
+    h.load_params(params)
+    h.call('dr_finalize_params', gpu.stream)
+    hm, hm3, um = gpu.forward_eval(h, ndm)
+    assert hm.shape == (2, 64, 64, 14) and um.shape == (2, 64, 64, 42)
+    ep = net.forward_eval(cfg, params, ndm)
+    for got, key in ((hm, 'hm_outs'), (hm3, 'hm3_outs'), (um, 'um_outs')):
+        assert np.abs(got - ep[key][-1]).max() < 5e-4, key
+    xyz = gpu.infer(h, ndm, cfgs, coms)
+    ref = pose.estimate_pose_mm(ep['hm_outs'][-1], ep['hm3_outs'][-1], ep['um_outs'][-1], ndm, cfgs, coms, out_hw=64)
+    assert pose.mean_jnt_error(xyz, ref) <= 0.1
+    h.close()

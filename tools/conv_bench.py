@@ -10,7 +10,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from densereg_amd import _lib  # noqa: E402
 
-TILES = {-1: 'auto', 0: '128x128', 1: '64x128', 2: '128x64', 3: '64x64', 4: '128x32', 5: '128x96'}
+TILES = {-1: 'auto', 0: '128x128', 1: '64x128', 2: '128x64', 3: '64x64', 4: '128x32', 5: '128x96', 6: '64x128 BK32'}
 ABL = {0: '', 1: 'no-refill', 2: 'no-mfma', 3: 'no-store', 4: 'BK=32'}
 
 
@@ -28,7 +28,7 @@ def main():
         np_ = -(-cout // 32) * 32
         variants = [(-1, 0)]
         if np_ % 128 == 0:
-            variants += [(0, 0), (1, 0), (0, 1), (0, 2)]
+            variants += [(0, 0), (1, 0)] + ([(6, 0)] if cin % 32 == 0 else [])
         elif np_ % 64 == 0:
             variants += [(2, 0), (3, 0)]
         elif np_ == 96:

@@ -13,5 +13,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_train -o trai
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_infer -o infer -- python $R/bench.py --mode infer --steps 10 --warmup 5 --no-cpu-baseline --no-profile > $R/gpurun_out/rocprof_infer.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $R/gpurun_out/pmc_fetch.log 2>&1; echo "rc=$?" >> $R/gpurun_out/pmc_fetch.log
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $R/gpurun_out/pmc_write.log 2>&1; echo "rc=$?" >> $R/gpurun_out/pmc_write.log
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch_infer -o fetch -- python $R/bench.py --mode infer --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $R/gpurun_out/pmc_fetch_infer.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write_infer -o write -- python $R/bench.py --mode infer --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $R/gpurun_out/pmc_write_infer.log 2>&1
 cd $R
 grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -3; tail -2 gpurun_out/smoke.log; cut -c1-330 gpurun_out/bench_train.json; echo; cut -c1-330 gpurun_out/bench_infer.json; echo; ls -la gpurun_out/pmc_fetch gpurun_out/pmc_write; tail -3 gpurun_out/pmc_fetch.log

@@ -18,6 +18,8 @@
 // dropout keep mask (x2); + residual;  optional per-channel sum / sum-of-squares of the RAW
 // accumulator for train-mode BatchReNorm (tf.nn.moments, ops.py:132) via fp64 atomics.
 #pragma once
+#include <type_traits>
+
 #include "dr_platform.h"
 
 namespace dr {
@@ -37,6 +39,7 @@ struct ConvParams {
     int drop_rng; unsigned long long drop_seed;      // drop_rng != 0: counter-based keep bit instead of `drop`
     const float* out_rowmask; float out_mask_thresh; // nullable: rows with out_rowmask[m] < thresh are not written
     double* stat_sum; double* stat_sq;               // nullable: per-channel moments of acc
+    const float* zeros;                              // >= 16 B of zeros in HBM: target of predicated-off loads
 };
 
 // stateless keep bit for dropout(0.5): splitmix64 finaliser of (seed, element index)
@@ -65,7 +68,6 @@ struct ConvTile {
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(kWTM % 32 == 0 && kWTN % 32 == 0, "wave tile must be made of 32x32 MFMA tiles");
     static_assert((BM * (kBK / 4)) % kThreads == 0, "A loader mapping");
-    static constexpr size_t kLdsBytes = size_t(2) * kBK * (kSA + kSB) * sizeof(float);
 };
 
 // ABL (profiling ablations, product code uses 0): 1 = no global->LDS refills after the first K-tile,
@@ -114,76 +116,84 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int y = rem / p.W, x = rem % p.W;
         unsigned mask = 0;
         if (ok) {
-            for (int t = 0; t < taps; ++t) {
-                const int yy = y + t / p.ksize - pad, xx = x + t % p.ksize - pad;
-                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1u << t;
-            }
+            int t = 0;                                     // no div/mod by the runtime ksize in here
+            for (int dy = -pad; dy <= pad; ++dy)
+                for (int dx = -pad; dx <= pad; ++dx, ++t) {
+                    const int yy = y + dy, xx = x + dx;
+                    if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1u << t;
+                }
         }
         a_taps[i] = mask;
         a_off[i] = ok ? (unsigned)((long)m * p.x_cs + p.x_coff + a_k4[i] * 4) : 0u;
     }
-    unsigned b_off[T::kBIters];
-    bool b_ok[T::kBIters];
-#pragma unroll
-    for (int i = 0; i < T::kBIters; ++i) {
-        const int idx = tid + i * T::kThreads;
-        const int krow = idx / (BN / 4), n4 = idx % (BN / 4);
-        b_ok[i] = krow < BK && n0 + n4 * 4 < p.Np;
-        b_off[i] = (unsigned)(krow * p.Np + n0 + n4 * 4);
-    }
+    // weight tile: thread -> (k row, 4 columns); at most two float4 per thread (BN = 128).  Scalars, not arrays:
+    // hipcc kept the two-element arrays in scratch once the K loop was unrolled by two.
+    static_assert(T::kBIters <= 2, "B loader handles at most two float4 per thread");
+    const int b_krow0 = tid / (BN / 4), b_n40 = tid % (BN / 4);
+    const int b_krow1 = (tid + T::kThreads) / (BN / 4), b_n41 = (tid + T::kThreads) % (BN / 4);
+    const bool b_ok0 = b_krow0 < BK && n0 + b_n40 * 4 < p.Np;
+    const bool b_ok1 = T::kBIters > 1 && b_krow1 < BK && n0 + b_n41 * 4 < p.Np;
+    const unsigned b_off0 = (unsigned)(b_krow0 * p.Np + n0 + b_n40 * 4);
+    const unsigned b_off1 = (unsigned)(b_krow1 * p.Np + n0 + b_n41 * 4);
 
     float4 a_reg[T::kAIters];
-    float4 b_reg[T::kBIters];
+    float4 b_reg0, b_reg1;
 
-    auto load_tile = [&](int t) {
-        const int tap = t / KT;                               // wave-uniform
-        const int kc = (t - tap * KT) * BK;
-        const int dy = tap / p.ksize - pad, dx = tap % p.ksize - pad;
-        const float* xbase = p.x + ((long)(dy * p.W + dx) * p.x_cs + kc);       // uniform: SGPR pair
-        const float* wbase = p.w + ((long)tap * p.Kp + kc) * p.Np;
-        const bool whole = kc + BK <= p.Cin;                  // uniform: no channel predicate needed
+    // Refill = UNCONDITIONAL loads: a predicated-off lane reads 16 B of zeros from p.zeros (pointer select,
+    // no branch).  With "v = 0; if (ok) v = load" hipcc copies the loaded value at the join and parks an
+    // s_waitcnt vmcnt(0) right behind every load, stalling the wave in front of the MFMAs the prefetch was meant
+    // to overlap.  The (tap, channel-chunk) cursor of the NEXT tile advances incrementally (no div/mod per tile).
+    int ld_kc = 0, ld_dy = -pad, ld_dx = -pad, ld_tap = 0;
+    const float* ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;      // wave-uniform cursors
+    const float* ld_w = p.w;
+    const bool ragged = (p.Cin & 3) != 0;                                  // uniform: Cin % 4 != 0
+    int a_nv[T::kAIters];                                                  // only meaningful on ragged tiles
+    auto load_tile = [&]() __attribute__((always_inline)) {
+        const bool tail = ld_kc + BK > p.Cin;                              // uniform: this chunk crosses Cin
 #pragma unroll
         for (int i = 0; i < T::kAIters; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((a_taps[i] >> tap) & 1u) {
-                const float* src = xbase + a_off[i];
-                if (whole) {
-                    v = *reinterpret_cast<const float4*>(src);
-                } else {
-                    const int c = kc + a_k4[i] * 4;
-                    if (c + 4 <= p.Cin) {
-                        v = *reinterpret_cast<const float4*>(src);
-                    } else if (c < p.Cin) {                   // ragged channel tail (Cin % 4 != 0)
-                        v.x = src[0];
-                        if (c + 1 < p.Cin) v.y = src[1];
-                        if (c + 2 < p.Cin) v.z = src[2];
-                    }
-                }
+            bool ok = (a_taps[i] >> ld_tap) & 1u;
+            int nv = 4;
+            if (tail) {
+                const int left = p.Cin - (ld_kc + a_k4[i] * 4);
+                nv = left < 0 ? 0 : (left > 4 ? 4 : left);
+                ok = ok && nv > 0;
             }
-            a_reg[i] = v;
+            const float* src = ok ? ld_x + ld_kc + a_off[i] : p.zeros;
+            a_reg[i] = *reinterpret_cast<const float4*>(src);
+            a_nv[i] = ok ? nv : 4;                                          // zeros need no masking
         }
-#pragma unroll
-        for (int i = 0; i < T::kBIters; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b_ok[i]) v = *reinterpret_cast<const float4*>(wbase + b_off[i]);
-            b_reg[i] = v;
+        b_reg0 = *reinterpret_cast<const float4*>(b_ok0 ? ld_w + b_off0 : p.zeros);
+        if constexpr (T::kBIters > 1) b_reg1 = *reinterpret_cast<const float4*>(b_ok1 ? ld_w + b_off1 : p.zeros);
+        // advance the cursor
+        ld_kc += BK;
+        ld_w += (long)BK * p.Np;
+        if (ld_kc >= p.Kp) {
+            ld_kc = 0;
+            ++ld_tap;
+            if (++ld_dx > pad) { ld_dx = -pad; ++ld_dy; }
+            ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](const int buf, bool was_tail) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < T::kAIters; ++i) {
             const int k = a_k4[i] * 4, r = a_row[i];
-            As[buf][k + 0][r] = a_reg[i].x;
-            As[buf][k + 1][r] = a_reg[i].y;
-            As[buf][k + 2][r] = a_reg[i].z;
-            As[buf][k + 3][r] = a_reg[i].w;
+            float4 v = a_reg[i];
+            if (ragged && was_tail) {                                       // uniform branch, rare layers only
+                const int nv = a_nv[i];
+                v.y = nv > 1 ? v.y : 0.f;
+                v.z = nv > 2 ? v.z : 0.f;
+                v.w = nv > 3 ? v.w : 0.f;
+            }
+            As[buf][k + 0][r] = v.x;
+            As[buf][k + 1][r] = v.y;
+            As[buf][k + 2][r] = v.z;
+            As[buf][k + 3][r] = v.w;
         }
-#pragma unroll
-        for (int i = 0; i < T::kBIters; ++i) {
-            const int idx = tid + i * T::kThreads;
-            const int krow = idx / (BN / 4);
-            const int n4 = idx % (BN / 4);
-            if (krow < BK) *reinterpret_cast<float4*>(&Bs[buf][krow][n4 * 4]) = b_reg[i];
+        if (b_krow0 < BK) *reinterpret_cast<float4*>(&Bs[buf][b_krow0][b_n40 * 4]) = b_reg0;
+        if constexpr (T::kBIters > 1) {
+            if (b_krow1 < BK) *reinterpret_cast<float4*>(&Bs[buf][b_krow1][b_n41 * 4]) = b_reg1;
         }
     };
 
@@ -195,68 +205,138 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
+    bool tail0 = BK > p.Cin;
+    load_tile();
+    store_tile(0, tail0);
     __syncthreads();
 
     const int lk = lane >> 5;          // which k of the pair this lane feeds
     const int li = lane & 31;
-    for (int t = 0; t < T_total; ++t) {
-        const int buf = t & 1;
-        if (ABL != 1 && t + 1 < T_total) load_tile(t + 1);
+    // The K loop is unrolled by two so that the LDS buffer index is a compile-time constant: every ds_read /
+    // ds_write address is then "base + immediate" instead of a per-access VALU add.
+    for (int t = 0; t < T_total; t += 2) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[T::kTM], b[T::kTN];
+        for (int buf = 0; buf < 2; ++buf) {
+            if (t + buf < T_total) {
+                const bool more = ABL != 1 && t + buf + 1 < T_total;
+                const bool was_tail = ld_kc + BK > p.Cin;                   // of the tile being fetched now
+                if (more) load_tile();
 #pragma unroll
-            for (int i = 0; i < T::kTM; ++i) a[i] = As[buf][2 * kk + lk][wm * T::kWTM + i * 32 + li];
+                for (int kk = 0; kk < BK / 2; ++kk) {
+                    float a[T::kTM], b[T::kTN];
 #pragma unroll
-            for (int j = 0; j < T::kTN; ++j) b[j] = Bs[buf][2 * kk + lk][wn * T::kWTN + j * 32 + li];
+                    for (int i = 0; i < T::kTM; ++i) a[i] = As[buf][2 * kk + lk][wm * T::kWTM + i * 32 + li];
 #pragma unroll
-            for (int i = 0; i < T::kTM; ++i)
+                    for (int j = 0; j < T::kTN; ++j) b[j] = Bs[buf][2 * kk + lk][wn * T::kWTN + j * 32 + li];
 #pragma unroll
-                for (int j = 0; j < T::kTN; ++j) {
-                    if (ABL == 2) acc[i][j][0] = fmaf(a[i], b[j], acc[i][j][0]);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < T::kTM; ++i)
+#pragma unroll
+                        for (int j = 0; j < T::kTN; ++j) {
+                            if (ABL == 2) acc[i][j][0] = fmaf(a[i], b[j], acc[i][j][0]);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        }
                 }
+                if (more) store_tile(buf ^ 1, was_tail);
+                __syncthreads();
+            }
         }
-        if (ABL != 1 && t + 1 < T_total) store_tile(buf ^ 1);
-        __syncthreads();
     }
 
     // ---- epilogue ----------------------------------------------------------------------------
     // D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // Every global read of the epilogue (output row mask, dropout keep bytes, residual) is issued as a batch of
+    // independent, unconditional loads BEFORE the first use (a masked-off lane reads element 0 and ignores it):
+    // written as "if (ok) v += res[...]" per element, hipcc serialises them behind s_waitcnt vmcnt(0) -- 16
+    // dependent HBM round trips per 32x32 tile, which was most of the run time of the short-K 1x1 layers.
+    // Indices are 32-bit element offsets from the (uniform) tensor base, so each access is "sgpr base + vgpr
+    // offset" and costs one address register; launch_conv_igemm rejects tensors of 2^32 elements or more.
+    double s1[T::kTN], s2[T::kTN];
 #pragma unroll
-    for (int j = 0; j < T::kTN; ++j) {
-        const int n = n0 + wn * T::kWTN + j * 32 + li;
-        const bool n_ok = n < p.Cout;
-        const float sc = (n_ok && p.scale) ? p.scale[n] : 1.f;
-        const float sh = (n_ok && p.shift) ? p.shift[n] : 0.f;
-        double s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < T::kTN; ++j) s1[j] = s2[j] = 0.0;
+    const bool dropping = p.drop || p.drop_rng;
 #pragma unroll
-        for (int i = 0; i < T::kTM; ++i) {
+    for (int i = 0; i < T::kTM; ++i) {
+        const int mb = m0 + wm * T::kWTM + i * 32 + 4 * lk;               // row of r = 0
+        unsigned rows = 0;                                                  // bit r: this lane writes row r
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * T::kWTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (ABL == 3 && acc[i][j][r] != 12345.678f) continue;
-                if (m < M && n_ok && !(p.out_rowmask && p.out_rowmask[m] < p.out_mask_thresh)) {
-                    const float raw = acc[i][j][r];
-                    s1 += (double)raw;
-                    s2 += (double)raw * (double)raw;
-                    float v = raw * sc + sh;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.drop) v = p.drop[(long)m * p.Cout + n] ? v * 2.f : 0.f;
-                    else if (p.drop_rng) v = dropout_keep(p.drop_seed, (unsigned long long)m * p.Cout + n) ? v * 2.f : 0.f;
-                    if (p.res) v += p.res[(long)m * p.res_cs + p.res_coff + n];
-                    p.y[(long)m * p.y_cs + p.y_coff + n] = v;
+        for (int r = 0; r < 16; ++r)
+            if (mb + (r & 3) + 8 * (r >> 2) < M) rows |= 1u << r;
+        if (p.out_rowmask) {
+            float om[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) om[r] = p.out_rowmask[((rows >> r) & 1u) ? (unsigned)(mb + (r & 3) + 8 * (r >> 2)) : 0u];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (om[r] < p.out_mask_thresh) rows &= ~(1u << r);
+        }
+#pragma unroll
+        for (int j = 0; j < T::kTN; ++j) {
+            const int n = n0 + wn * T::kWTN + j * 32 + li;
+            const bool n_ok = n < p.Cout;
+            const float sc = (n_ok && p.scale) ? p.scale[n] : 1.f;
+            const float sh = (n_ok && p.shift) ? p.shift[n] : 0.f;
+            const unsigned rows_j = n_ok ? rows : 0u;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {                         // 8 rows at a time: bounds the VGPR peak
+                float rv[8];
+                unsigned keep = 0xFFu;
+                if (p.res) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = half * 8 + q;
+                        const unsigned m = (unsigned)(mb + (r & 3) + 8 * (r >> 2));
+                        rv[q] = p.res[((rows_j >> r) & 1u) ? m * (unsigned)p.res_cs + (unsigned)(p.res_coff + n) : 0u];
+                    }
+                }
+                if (p.drop) {
+                    unsigned char dv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = half * 8 + q;
+                        const unsigned m = (unsigned)(mb + (r & 3) + 8 * (r >> 2));
+                        dv[q] = p.drop[((rows_j >> r) & 1u) ? m * (unsigned)p.Cout + (unsigned)n : 0u];
+                    }
+                    keep = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) keep |= (dv[q] ? 1u : 0u) << q;
+                } else if (p.drop_rng) {
+                    keep = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = half * 8 + q;
+                        const unsigned long long m = (unsigned long long)(mb + (r & 3) + 8 * (r >> 2));
+                        keep |= (dropout_keep(p.drop_seed, m * p.Cout + n) ? 1u : 0u) << q;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = half * 8 + q;
+                    if (ABL == 3 && acc[i][j][r] != 12345.678f) continue;
+                    if ((rows_j >> r) & 1u) {
+                        const unsigned m = (unsigned)(mb + (r & 3) + 8 * (r >> 2));
+                        const float raw = acc[i][j][r];
+                        s1[j] += (double)raw;
+                        s2[j] += (double)raw * (double)raw;
+                        float v = raw * sc + sh;
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (dropping) v = ((keep >> q) & 1u) ? v * 2.f : 0.f;
+                        if (p.res) v += rv[q];
+                        p.y[m * (unsigned)p.y_cs + (unsigned)(p.y_coff + n)] = v;
+                    }
                 }
             }
         }
-        if (p.stat_sum) {
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (lk == 0 && n_ok) {
-                atomicAdd(&p.stat_sum[n], s1);
-                atomicAdd(&p.stat_sq[n], s2);
+    }
+    if (p.stat_sum) {
+#pragma unroll
+        for (int j = 0; j < T::kTN; ++j) {
+            const int n = n0 + wn * T::kWTN + j * 32 + li;
+            double a = s1[j], b = s2[j];
+            a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 32);
+            if (lk == 0 && n < p.Cout) {
+                atomicAdd(&p.stat_sum[n], a);
+                atomicAdd(&p.stat_sq[n], b);
             }
         }
     }

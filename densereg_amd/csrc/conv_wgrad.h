@@ -51,6 +51,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int steps = m_begin < m_end ? (int)((m_end - m_begin + BK - 1) / BK) : 0;
 
     float4 xr[ITERS], gr[ITERS];
+    int xnv[ITERS], gnv[ITERS];        // valid leading components of the staged float4 (0 = nothing)
+    // unconditional loads + zero-select at store time (see conv_igemm.h: a branchy load makes hipcc wait right
+    // behind every load and serialises the refill in front of the MFMAs)
     auto load = [&](int st) {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
@@ -58,35 +61,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             const int row = idx / (T / 4);
             const int c4 = (idx % (T / 4)) * 4;
             const long m = m_begin + (long)st * BK + row;
-            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), gv = xv;
-            if (m < m_end) {
-                // gradient row
-                const int co = co0 + c4;
-                if (co < p.Cout) {
-                    const float* src = p.g + m * p.g_cs + p.g_coff + co;
-                    if (co + 4 <= p.Cout) gv = *reinterpret_cast<const float4*>(src);
-                    else { gv.x = src[0]; if (co + 1 < p.Cout) gv.y = src[1]; if (co + 2 < p.Cout) gv.z = src[2]; }
-                }
-                // shifted input row
-                const int ci = ci0 + c4;
-                bool ok = ci < p.Cin;
-                long ms = m;
-                if (ok && p.ksize > 1) {
-                    const int rem = (int)(m % HW);
-                    const int yy = rem / p.W + dy, xx = rem % p.W + dx;
-                    ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-                    ms = m + (long)dy * p.W + dx;
-                }
-                if (ok && p.rowmask) ok = !(p.rowmask[ms] < p.mask_thresh);
-                if (ok) {
-                    const float* src = p.x + ms * p.x_cs + p.x_coff + ci;
-                    if (ci + 4 <= p.Cin) xv = *reinterpret_cast<const float4*>(src);
-                    else { xv.x = src[0]; if (ci + 1 < p.Cin) xv.y = src[1]; if (ci + 2 < p.Cin) xv.z = src[2]; }
-                }
+            const bool in_range = m < m_end;
+            // gradient row
+            const int gleft = p.Cout - (co0 + c4);
+            int gv = gleft < 0 ? 0 : (gleft > 4 ? 4 : gleft);
+            if (!in_range) gv = 0;
+            // shifted input row
+            const int xleft = p.Cin - (ci0 + c4);
+            int xv = xleft < 0 ? 0 : (xleft > 4 ? 4 : xleft);
+            long ms = m;
+            bool ok = in_range;
+            if (p.ksize > 1) {
+                const int rem = (int)((in_range ? m : 0) % HW);
+                const int yy = rem / p.W + dy, xx = rem % p.W + dx;
+                ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                ms = m + (long)dy * p.W + dx;
             }
-            xr[i] = xv;
-            gr[i] = gv;
+            if (!ok) { xv = 0; ms = 0; }
+            if (p.rowmask && xv && p.rowmask[ms] < p.mask_thresh) xv = 0;
+            const float* gsrc = gv ? p.g + m * p.g_cs + p.g_coff + co0 + c4 : p.g;
+            const float* xsrc = xv ? p.x + ms * p.x_cs + p.x_coff + ci0 + c4 : p.x;
+            gr[i] = *reinterpret_cast<const float4*>(gsrc);
+            xr[i] = *reinterpret_cast<const float4*>(xsrc);
+            gnv[i] = gv;
+            xnv[i] = xv;
         }
+    };
+    auto zsel = [](float4 v, int nv) {
+        return make_float4(nv > 0 ? v.x : 0.f, nv > 1 ? v.y : 0.f, nv > 2 ? v.z : 0.f, nv > 3 ? v.w : 0.f);
     };
     auto store = [&](int buf) {
 #pragma unroll
@@ -94,8 +96,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             const int idx = tid + i * 256;
             const int row = idx / (T / 4);
             const int c4 = (idx % (T / 4)) * 4;
-            *reinterpret_cast<float4*>(&Xs[buf][row][c4]) = xr[i];
-            *reinterpret_cast<float4*>(&Gs[buf][row][c4]) = gr[i];
+            *reinterpret_cast<float4*>(&Xs[buf][row][c4]) = zsel(xr[i], xnv[i]);
+            *reinterpret_cast<float4*>(&Gs[buf][row][c4]) = zsel(gr[i], gnv[i]);
         }
     };
 

@@ -66,20 +66,16 @@ int conv_tile_id(const ConvParams& p) {
 }
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
-    if (p.x_cs % 4 || p.x_coff % 4 || p.Kp % 16 || p.Np % 32) return -1;
+    if (p.x_cs % 4 || p.x_coff % 4 || p.Kp % 16 || p.Np % 32 || !p.zeros) return -1;
+    // the kernel addresses every tensor with 32-bit element offsets from its base pointer
+    const long long M = (long long)p.B * p.H * p.W;
+    const long long widest = std::max(std::max((long long)p.x_cs, (long long)p.y_cs), std::max((long long)p.res_cs, (long long)p.Cout));
+    if (M * widest >= (1ll << 32)) return -1;
     switch (conv_tile_id(p)) {
         case KID_CONV_128x128: launch_cfg<128, 128, 2, 2>(p, s); break;
         case KID_CONV_64x128: launch_cfg<64, 128, 2, 2>(p, s); break;
         case KID_CONV_128x64: launch_cfg<128, 64, 2, 2>(p, s); break;
         case KID_CONV_64x64: launch_cfg<64, 64, 2, 2>(p, s); break;
-        case KID_CONV_128x96: launch_cfg<128, 96, 4, 1>(p, s); break;
-        case KID_CONV_64x128_K32: {
-            if (p.Kp % 32) return -1;
-            const int M = p.B * p.H * p.W;
-            dim3 grid(dr_ceil_div(M, 64), dr_ceil_div(p.Np, 128));
-            DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 0, 32>), grid, dim3(256), 0, s, p);
-            break;
-        }
         default: launch_cfg<128, 32, 4, 1>(p, s); break;
     }
     return 0;
@@ -335,7 +331,7 @@ void add_param(dr_handle* h, const std::string& name, std::initializer_list<int>
 static void free_all(dr_handle* h) {
     for (void* p : {(void*)h->flat_param, (void*)h->flat_grad, (void*)h->adam_m, (void*)h->adam_v, (void*)h->flat_state, (void*)h->flat_state_next,
                     (void*)h->shadow, (void*)h->wp, (void*)h->wpT, (void*)h->fold, (void*)h->stats, (void*)h->bnc,
-                    (void*)h->act_arena, (void*)h->grad_arena, (void*)h->scratch, (void*)h->tiny, (void*)h->tiny_ext,
+                    (void*)h->act_arena, (void*)h->grad_arena, (void*)h->scratch, (void*)h->tiny, (void*)h->tiny_ext, (void*)h->zeros,
                     (void*)h->losses, (void*)h->reg_segs, (void*)h->loss_acc, (void*)h->bn_coef, (void*)h->wg_partial})
         if (p) rt::dfree(p);
 }
@@ -434,6 +430,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
     alloc_f(h->tiny, MB * h->map_hw * h->map_hw);
     alloc_f(h->tiny_ext, MB * h->map_hw * h->map_hw);
     alloc_f(h->losses, 4);
+    alloc_f(h->zeros, 64);
     if (cfg->training) {
         alloc_f(h->flat_grad, nt);
         alloc_f(h->adam_m, nt);
@@ -475,6 +472,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
     }
     // pad channels are never written by the kernels: keep them (and everything else) finite
     rt::memset_async(h->act_arena, 0, h->n_act * sizeof(float), nullptr);
+    rt::memset_async(h->zeros, 0, 64 * sizeof(float), nullptr);
     rt::memset_async(h->flat_param, 0, nt * sizeof(float), nullptr);
     rt::memset_async(h->flat_state, 0, std::max<size_t>(ns, 1) * sizeof(float), nullptr);
     if (cfg->training) {
@@ -648,6 +646,7 @@ static int run_conv_eval(dr_handle* h, const Op& op, int B, hipStream_t s) {
     p.relu = c.relu;
     if (op.in2.valid()) { p.res = op.in2.t->p; p.res_cs = op.in2.t->cs; p.res_coff = op.in2.coff; }
     if (op.masked) { p.rowmask = h->tiny; p.mask_thresh = -0.9f; }
+    p.zeros = h->zeros;
     ProfScope ps(h, s, conv_tile_id(p), 2.0 * B * c.H * c.W * c.k * c.k * c.cin * c.cout,
                  4.0 * B * c.H * c.W * ((double)c.cin + c.cout + (op.in2.valid() ? c.cout : 0)));
     if (launch_conv_igemm(p, s)) DR_FAIL(h, DR_E_STATE, "conv %s: unsupported layout", c.name.c_str());
@@ -828,9 +827,14 @@ extern "C" int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, cons
     p.scale = scale; p.shift = shift; p.relu = relu; p.res = res; p.res_cs = res_cs; p.res_coff = 0;
     p.rowmask = rowmask; p.mask_thresh = thresh;
     p.stat_sum = stat; p.stat_sq = stat ? stat + Cout : nullptr;
+    float* zeros = (float*)rt::dmalloc(256);
+    if (!zeros) return DR_E_NOMEM;
+    rt::memset_async(zeros, 0, 256, s);
+    p.zeros = zeros;
     int rc = launch_conv_igemm(p, s);
     rt::sync_stream(s);
     rt::dfree(wp);
+    rt::dfree(zeros);
     std::string m;
     if (rc || rt::last_error(&m)) return DR_E_DEVICE;
     return DR_OK;
@@ -861,15 +865,23 @@ extern "C" int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, 
     ConvParams p{};
     p.x = x; p.x_cs = x_cs; p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.ksize = k;
     p.w = wp; p.Kp = Kp; p.Np = Np; p.y = y; p.y_cs = y_cs; p.Cout = Cout; p.scale = sc; p.shift = sc; p.relu = 1;
+    float* zeros = (float*)rt::dmalloc(256);
+    if (!zeros) return DR_E_NOMEM;
+    rt::memset_async(zeros, 0, 256, nullptr);
+    p.zeros = zeros;
     g_force_tile = tile;
+    float* res = nullptr;
+    if (abl == 5) {                                     // product kernel with a fused residual add
+        res = (float*)rt::dmalloc(M * y_cs * sizeof(float));
+        if (!res) return DR_E_NOMEM;
+        rt::memset_async(res, 0, M * y_cs * sizeof(float), nullptr);
+        p.res = res; p.res_cs = y_cs;
+    }
     auto launch = [&]() {
         const int Mi = (int)M;
-        if (abl > 0) {
+        if (abl > 0 && abl < 4) {
             dim3 grid(dr_ceil_div(Mi, 128), dr_ceil_div(Np, 128));
-            if (abl == 4) {
-                if (Kp % 32) { p.Kp = dr_round_up(Kp, 32); }      // bench only: weights buffer is over-allocated below
-                DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 0, 32>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
-            } else if (abl == 1) DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
+            if (abl == 1) DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
             else if (abl == 2) DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
             else DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
         } else {
@@ -886,14 +898,60 @@ extern "C" int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, 
     *ms_out = rt::event_elapsed_ms(a, b) / iters;
     g_force_tile = -1;
     rt::event_destroy(a); rt::event_destroy(b);
-    rt::dfree(x); rt::dfree(y); rt::dfree(wp); rt::dfree(sc);
+    rt::dfree(x); rt::dfree(y); rt::dfree(wp); rt::dfree(sc); rt::dfree(zeros);
+    if (res) rt::dfree(res);
+    std::string m;
+    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
+}
+
+// Sustained fp32 MFMA rate of the chip (no memory traffic): every wave runs `iters` rounds of four independent
+// v_mfma_f32_32x32x2_f32 chains.  zero_data = 1 feeds zeros (the DVFS best case), 0 feeds varied values.
+// Documents the clock-limited ceiling under the nominal 157.3 TFLOP/s (profiles/*_conv_microbench.md).
+namespace dr {
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float seed, float* out) {
+    dr_f32x16 acc[4];
+    for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const float a = seed * (float)((threadIdx.x * 37 + blockIdx.x * 11) % 61 - 30);
+    const float b = seed * (float)((threadIdx.x * 13 + blockIdx.x * 7) % 53 - 26);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 16; ++r) s += acc[j][r];
+    if (s == 12345.678f) out[0] = s;                   // keeps the chains alive, never true
+}
+}  // namespace dr
+
+extern "C" int dr_dbg_mfma_peak(int iters, int waves_per_simd, int zero_data, float* tflops_out) {
+    if (!tflops_out || iters < 1 || waves_per_simd < 1 || waves_per_simd > 8) return DR_E_INVALID;
+    float* out = (float*)rt::dmalloc(256);
+    if (!out) return DR_E_NOMEM;
+    const int blocks = 256 * waves_per_simd;           // one 4-wave block per CU per resident wave slot
+    const float seed = zero_data ? 0.f : 0.03125f;
+    for (int i = 0; i < 2; ++i) DR_LAUNCH(dr::mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t) nullptr, iters, seed, out);
+    rt::sync_stream(nullptr);
+    rt::Event a = rt::event_create(), b = rt::event_create();
+    rt::event_record(a, nullptr);
+    for (int i = 0; i < 5; ++i) DR_LAUNCH(dr::mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t) nullptr, iters, seed, out);
+    rt::event_record(b, nullptr);
+    rt::sync_stream(nullptr);
+    const double ms = rt::event_elapsed_ms(a, b) / 5;
+    const double flops = (double)blocks * 4 /*waves*/ * iters * 16 /*mfma*/ * (2.0 * 32 * 32 * 2);
+    *tflops_out = (float)(flops / (ms * 1e-3) / 1e12);
+    rt::event_destroy(a); rt::event_destroy(b);
+    rt::dfree(out);
     std::string m;
     return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
 }
 
 // force the conv tile choice of every following launch (-1 = heuristic); tests sweep all tile shapes with it
 extern "C" int dr_dbg_force_tile(int tile) {
-    if (tile < -1 || tile > KID_CONV_64x128_K32) return DR_E_INVALID;
+    if (tile < -1 || tile > KID_CONV_128x32) return DR_E_INVALID;
     g_force_tile = tile;
     return DR_OK;
 }

@@ -18,11 +18,16 @@ int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, const float* x,
 
 /* Micro-benchmark one conv shape on self-allocated buffers: average milliseconds per launch.
  * tile = -1 (heuristic) or a tile id (0 128x128, 1 64x128, 2 128x64, 3 64x64, 4 128x32);
- * abl = 0 product kernel, 1/2/3 = ablations of the 128x128 kernel (no refills / no MFMA / no stores). */
+ * abl = 0 product kernel, 1/2/3 = ablations of the 128x128 kernel (no refills / no MFMA / no stores),
+ * 5 = product kernel with the fused residual add. */
 int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, int tile, int abl, int iters, float* ms_out);
 
-/* Force the conv tile of every following launch (-1 = heuristic; ids as in dr_dbg_conv_bench, 5 = 128x96,
- * 6 = 64x128 with BK=32).  Process-global; tests use it to check every tile shape against the reference. */
+/* Sustained fp32 MFMA TFLOP/s of the device without memory traffic (register-only chains of
+ * v_mfma_f32_32x32x2_f32; `waves_per_simd` resident waves; zero_data = 1 feeds zeros, the DVFS best case). */
+int dr_dbg_mfma_peak(int iters, int waves_per_simd, int zero_data, float* tflops_out);
+
+/* Force the conv tile of every following launch (-1 = heuristic; ids as in dr_dbg_conv_bench).
+ * Process-global; tests use it to check every tile shape against the reference. */
 int dr_dbg_force_tile(int tile);
 
 /* Per-kernel timing with HIP events on the caller's stream (bench.py roofline leg).  While enabled,

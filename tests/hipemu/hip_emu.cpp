@@ -165,16 +165,6 @@ struct Pool {
             }
         }
     }
-    void run(Job& j, int nworkers) {
-        std::unique_lock<std::mutex> l(mu);
-        job = &j;
-        wanted = nworkers;
-        running = nworkers;
-        ++epoch;
-        cv_work.notify_all();
-        cv_done.wait(l, [&] { return running == 0; });
-        wanted = 0;
-    }
 };
 }  // namespace
 
@@ -193,7 +183,6 @@ void launch_impl(dim3 grid, dim3 block, size_t smem, const std::function<void()>
         return;
     }
     // helpers pull blocks from the shared counter while the caller does the same
-    std::thread* dummy = nullptr; (void)dummy;
     {
         std::unique_lock<std::mutex> l(pool.mu);
         pool.job = &job;

@@ -10,8 +10,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from densereg_amd import _lib  # noqa: E402
 
-TILES = {-1: 'auto', 0: '128x128', 1: '64x128', 2: '128x64', 3: '64x64', 4: '128x32', 5: '128x96', 6: '64x128 BK32'}
-ABL = {0: '', 1: 'no-refill', 2: 'no-mfma', 3: 'no-store', 4: 'BK=32'}
+TILES = {-1: 'auto', 0: '128x128', 1: '64x128', 2: '128x64', 3: '64x64', 4: '128x32'}
+ABL = {0: '', 1: 'no-refill', 2: 'no-mfma', 3: 'no-store', 5: '+residual'}
 
 
 def main():
@@ -21,18 +21,24 @@ def main():
               (32, 256, 512, 1), (32, 256, 128, 1), (32, 128, 256, 1), (32, 128, 64, 1), (32, 64, 128, 1),
               (32, 64, 64, 3), (32, 160, 256, 1), (32, 80, 80, 3), (32, 65, 65, 3), (32, 131, 65, 1), (32, 160, 80, 1), (16, 64, 64, 3), (16, 128, 64, 1), (8, 64, 64, 3),
               (4, 64, 64, 3), (64, 32, 64, 1), (64, 16, 16, 3)]
+    print('sustained fp32 MFMA rate, register-only chains (nominal peak 157.3 TFLOP/s):\n')
+    print('| waves/SIMD | data | TFLOP/s |\n|---:|---|---:|')
+    for wps in (1, 2, 4):
+        for zero in (0, 1):
+            tf = C.c_float()
+            rc = lib.dr_dbg_mfma_peak(20000, wps, zero, C.byref(tf))
+            print('| %d | %s | %s |' % (wps, 'zeros' if zero else 'varied', '%.1f' % tf.value if rc == 0 else 'rc=%d' % rc))
+    print()
     print('| HxW | Cin | Cout | k | variant | us | TFLOP/s | % of 157.3 |')
     print('|---:|---:|---:|---:|---|---:|---:|---:|')
     for hw, cin, cout, k in shapes:
         flops = 2.0 * B * hw * hw * k * k * cin * cout
         np_ = -(-cout // 32) * 32
-        variants = [(-1, 0)]
+        variants = [(-1, 0), (-1, 5)]
         if np_ % 128 == 0:
-            variants += [(0, 0), (1, 0)] + ([(6, 0)] if cin % 32 == 0 else [])
+            variants += [(0, 0), (1, 0), (0, 1), (0, 2)]
         elif np_ % 64 == 0:
             variants += [(2, 0), (3, 0)]
-        elif np_ == 96:
-            variants += [(4, 0), (5, 0)]
         for tile, abl in variants:
             ms = C.c_float()
             rc = lib.dr_dbg_conv_bench(B, hw, hw, cin, cout, k, tile, abl, 20, C.byref(ms))

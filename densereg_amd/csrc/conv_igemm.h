@@ -5,14 +5,21 @@
 //
 //   GEMM view:  M = B*H*W output pixels,  N = Cout,  K = taps*Cin
 //   A[m][k]   = x[b, y+dy, x+dx, c]   gathered on the fly (zero outside the image: TF 'SAME')
-//   B[k][n]   = packed weights [tap][Kp][Np]  (HWIO with Cin->Kp, Cout->Np zero padding)
-//   D         = v_mfma_f32_32x32x2_f32 chains: exact fp32 (one rounding per product, k-ordered),
+//   B[k][n]   = packed weights [Kp/16][tap][Np][16]: the K-tile order of the main loop, so one weight tile
+//               (BN rows x 16 k) is one contiguous block (HWIO transposed, Cin->Kp, Cout->Np zero padded)
+//   D         = v_mfma_f32_32x32x2_f32 chains: exact fp32 (one rounding per product, fixed k order),
 //               157 TFLOP/s peak on gfx950 -- the roofline this kernel is priced against.
 //
 // Block = 256 threads = 4 waves; wave tile = (BM/WM) x (BN/WN) made of 32x32 MFMA tiles.
-// LDS holds As[BK][BM(+pad)] (k-major, so a lane's A fragment A[i=l&31][k=l>>5] is a
-// conflict-free row read) and Bs[BK][BN]; both are double buffered with register prefetch of the
-// next K-tile, one barrier per K-tile.
+// LDS holds As[BM][BK+4] and Bs[BN][BK+4], both k-CONTIGUOUS -- the layout the operands have in HBM, so a
+// refill is one 16-byte global load and one ds_write_b128 per thread and operand.  The MFMA sums over two k
+// slots (lane>>5); which two k values a step pairs up is free, so lane (i, lk) fetches k = 8g + 4*lk + {0..3}
+// with ONE ds_read_b128 and feeds them to four consecutive MFMA steps: step s multiplies k = 8g+s and
+// 8g+4+s.  That is a quarter of the LDS instructions of a dword-per-step fragment read.  Rows are unpadded
+// (BK floats); the 16-byte slot of (row, k4) is XOR-swizzled to k4 ^ ((row >> 2) & 3), which makes both the
+// ds_read_b128 lane groups (16 rows, one k4) and the ds_write_b128 groups (2 rows x 4 k4) bank-conflict free
+// (SQ_LDS_BANK_CONFLICT was a third of the LDS cycles with a padded, unswizzled layout).
+// Both tiles are double buffered with register prefetch of the next K-tile, one barrier per K-tile.
 //
 // Epilogue (per lane = one output channel, 16 rows):  v = acc*scale[n] + shift[n]; relu;
 // dropout keep mask (x2); + residual;  optional per-channel sum / sum-of-squares of the RAW
@@ -55,31 +62,36 @@ template <int BM, int BN, int WM, int WN, int BK_ = 16>
 struct ConvTile {
     static constexpr int kBK = BK_;
     static constexpr int kThreads = 256;
-    // As row stride: the transposing ds_write_b32 of (k4, m) lane pairs is conflict-free when
-    // 4*kSA*k4 mod 32 spreads over distinct bank groups: kSA = 2 (mod 8) for BK=16, odd for BK=32
-    static constexpr int kSA = BM + (BK_ == 16 ? 2 : 1);
-    static constexpr int kSB = BN;
+    static constexpr int kSK = BK_;               // LDS row stride (floats) of both operand tiles: unpadded, swizzled
+    static_assert(BK_ == 16, "the slot swizzle below assumes four 16-byte slots per row");
     static constexpr int kWTM = BM / WM;          // wave tile rows
     static constexpr int kWTN = BN / WN;
     static constexpr int kTM = kWTM / 32;
     static constexpr int kTN = kWTN / 32;
     static constexpr int kAIters = (BM * (kBK / 4)) / kThreads;
-    static constexpr int kBIters = (kBK * (BN / 4) + kThreads - 1) / kThreads;
+    static constexpr int kBIters = (BN * (kBK / 4) + kThreads - 1) / kThreads;
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(kWTM % 32 == 0 && kWTN % 32 == 0, "wave tile must be made of 32x32 MFMA tiles");
     static_assert((BM * (kBK / 4)) % kThreads == 0, "A loader mapping");
 };
 
 // ABL (profiling ablations, product code uses 0): 1 = no global->LDS refills after the first K-tile,
-// 2 = MFMA replaced by one VALU fma per fragment pair, 3 = no epilogue stores.
+// 2 = MFMA replaced by one VALU fma per fragment pair, 3 = no epilogue stores, 4 = refill loads issued and
+// waited for but not written to LDS, 5 = LDS refill writes (of stale registers) without the global loads.
+// Resident waves per SIMD the register allocator must leave room for.  M = 40960 rows (B=40 at 32x32) gives
+// 640 row blocks of 64: with Np = 256 / 512 that is exactly 5 / 10 workgroups per CU, so five resident
+// workgroups finish in whole rounds, while four leave a last round with one lonely workgroup per CU whose
+// load latency nothing hides (measured: a quarter of the kernel time).
+template <int BM, int BN>
+constexpr int conv_min_waves() { return BM * BN >= 128 * 128 ? 3 : 5; }
+
 template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (conv_min_waves<BM, BN>())) void conv_igemm_kernel(const ConvParams p) {
     using T = ConvTile<BM, BN, WM, WN, BK_>;
     constexpr int BK = T::kBK;
-    constexpr int SA = T::kSA;
-    constexpr int SB = T::kSB;
-    __shared__ float As[2][BK][SA];
-    __shared__ float Bs[2][BK][SB];
+    constexpr int SK = T::kSK;
+    __shared__ __attribute__((aligned(16))) float As[2][BM][SK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][SK];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -126,15 +138,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         a_taps[i] = mask;
         a_off[i] = ok ? (unsigned)((long)m * p.x_cs + p.x_coff + a_k4[i] * 4) : 0u;
     }
-    // weight tile: thread -> (k row, 4 columns); at most two float4 per thread (BN = 128).  Scalars, not arrays:
-    // hipcc kept the two-element arrays in scratch once the K loop was unrolled by two.
+    // weight tile: thread -> (output channel row, 4 consecutive k); at most two float4 per thread (BN = 128).
+    // Scalars, not arrays: hipcc kept two-element arrays in scratch once the K loop was unrolled by two.
     static_assert(T::kBIters <= 2, "B loader handles at most two float4 per thread");
-    const int b_krow0 = tid / (BN / 4), b_n40 = tid % (BN / 4);
-    const int b_krow1 = (tid + T::kThreads) / (BN / 4), b_n41 = (tid + T::kThreads) % (BN / 4);
-    const bool b_ok0 = b_krow0 < BK && n0 + b_n40 * 4 < p.Np;
-    const bool b_ok1 = T::kBIters > 1 && b_krow1 < BK && n0 + b_n41 * 4 < p.Np;
-    const unsigned b_off0 = (unsigned)(b_krow0 * p.Np + n0 + b_n40 * 4);
-    const unsigned b_off1 = (unsigned)(b_krow1 * p.Np + n0 + b_n41 * 4);
+    const int b_row0 = tid / (BK / 4), b_row1 = (tid + T::kThreads) / (BK / 4), b_k4 = tid % (BK / 4);
+    const bool b_ok0 = b_row0 < BN && n0 + b_row0 < p.Np;
+    const bool b_ok1 = T::kBIters > 1 && b_row1 < BN && n0 + b_row1 < p.Np;
+    const unsigned b_off0 = (unsigned)((n0 + b_row0) * BK + b_k4 * 4);      // = n0*BK + 4*tid: fully coalesced
+    const unsigned b_off1 = (unsigned)((n0 + b_row1) * BK + b_k4 * 4);
 
     float4 a_reg[T::kAIters];
     float4 b_reg0, b_reg1;
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // Refill = UNCONDITIONAL loads: a predicated-off lane reads 16 B of zeros from p.zeros (pointer select,
     // no branch).  With "v = 0; if (ok) v = load" hipcc copies the loaded value at the join and parks an
     // s_waitcnt vmcnt(0) right behind every load, stalling the wave in front of the MFMAs the prefetch was meant
-    // to overlap.  The (tap, channel-chunk) cursor of the NEXT tile advances incrementally (no div/mod per tile).
+    // to overlap.  The (channel-chunk, tap) cursor of the NEXT tile advances incrementally (no div/mod per tile).
     int ld_kc = 0, ld_dy = -pad, ld_dx = -pad, ld_tap = 0;
     const float* ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;      // wave-uniform cursors
     const float* ld_w = p.w;
@@ -165,15 +176,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
         b_reg0 = *reinterpret_cast<const float4*>(b_ok0 ? ld_w + b_off0 : p.zeros);
         if constexpr (T::kBIters > 1) b_reg1 = *reinterpret_cast<const float4*>(b_ok1 ? ld_w + b_off1 : p.zeros);
-        // advance the cursor
-        ld_kc += BK;
-        ld_w += (long)BK * p.Np;
-        if (ld_kc >= p.Kp) {
-            ld_kc = 0;
-            ++ld_tap;
-            if (++ld_dx > pad) { ld_dx = -pad; ++ld_dy; }
-            ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;
+        // advance the cursor: taps innermost.  The nine taps of one 16-channel chunk re-read the same 64-byte
+        // pixel slices (shifted by a pixel), one K-tile apart, so they hit in L1/L2; with the channel sweep
+        // innermost the re-read came 16 K-tiles later, after the slice had left this XCD's 4 MB L2.
+        ++ld_tap;
+        if (++ld_dx > pad) { ld_dx = -pad; ++ld_dy; }
+        if (ld_tap == taps) {
+            ld_tap = 0;
+            ld_dy = ld_dx = -pad;
+            ld_kc += BK;
         }
+        ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;
+        ld_w += p.Np * BK;                                                 // packed in exactly this order
     };
     auto store_tile = [&](const int buf, bool was_tail) __attribute__((always_inline)) {
 #pragma unroll
@@ -186,14 +200,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 v.z = nv > 2 ? v.z : 0.f;
                 v.w = nv > 3 ? v.w : 0.f;
             }
-            As[buf][k + 0][r] = v.x;
-            As[buf][k + 1][r] = v.y;
-            As[buf][k + 2][r] = v.z;
-            As[buf][k + 3][r] = v.w;
+            *reinterpret_cast<float4*>(&As[buf][r][k ^ ((r & 12))]) = v;      // slot k4 ^ ((r>>2)&3), in floats
         }
-        if (b_krow0 < BK) *reinterpret_cast<float4*>(&Bs[buf][b_krow0][b_n40 * 4]) = b_reg0;
+        if (b_row0 < BN) *reinterpret_cast<float4*>(&Bs[buf][b_row0][(b_k4 * 4) ^ (b_row0 & 12)]) = b_reg0;
         if constexpr (T::kBIters > 1) {
-            if (b_krow1 < BK) *reinterpret_cast<float4*>(&Bs[buf][b_krow1][b_n41 * 4]) = b_reg1;
+            if (b_row1 < BN) *reinterpret_cast<float4*>(&Bs[buf][b_row1][(b_k4 * 4) ^ (b_row1 & 12)]) = b_reg1;
         }
     };
 
@@ -210,37 +221,55 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     store_tile(0, tail0);
     __syncthreads();
 
+    float abl_sink = 0.f;              // ABL 4 only
     const int lk = lane >> 5;          // which k of the pair this lane feeds
     const int li = lane & 31;
-    // The K loop is unrolled by two so that the LDS buffer index is a compile-time constant: every ds_read /
-    // ds_write address is then "base + immediate" instead of a per-access VALU add.
-    for (int t = 0; t < T_total; t += 2) {
+    // One K-tile: prefetch tile t+1 into registers, MFMA over tile t from LDS buffer `buf`, park t+1 in the other
+    // buffer, barrier.  `buf` is a compile-time constant in every call (the K loop below is unrolled by two), so
+    // each ds_read / ds_write address is "base + immediate" instead of a per-access VALU add.
+    auto k_tile = [&](const int buf, const bool more_) __attribute__((always_inline)) {
+        const bool more = ABL != 1 && more_;
+        const bool was_tail = ld_kc + BK > p.Cin;                           // of the tile being fetched now
+        if (more && ABL != 5) load_tile();
+        float4 a4[BK / 8][T::kTM], b4[BK / 8][T::kTN];          // every fragment of this K-tile, read up front
 #pragma unroll
-        for (int buf = 0; buf < 2; ++buf) {
-            if (t + buf < T_total) {
-                const bool more = ABL != 1 && t + buf + 1 < T_total;
-                const bool was_tail = ld_kc + BK > p.Cin;                   // of the tile being fetched now
-                if (more) load_tile();
+        for (int g = 0; g < BK / 8; ++g) {
 #pragma unroll
-                for (int kk = 0; kk < BK / 2; ++kk) {
-                    float a[T::kTM], b[T::kTN];
+            for (int i = 0; i < T::kTM; ++i)
+                a4[g][i] = *reinterpret_cast<const float4*>(&As[buf][wm * T::kWTM + i * 32 + li][(g * 8 + lk * 4) ^ (li & 12)]);
 #pragma unroll
-                    for (int i = 0; i < T::kTM; ++i) a[i] = As[buf][2 * kk + lk][wm * T::kWTM + i * 32 + li];
-#pragma unroll
-                    for (int j = 0; j < T::kTN; ++j) b[j] = Bs[buf][2 * kk + lk][wn * T::kWTN + j * 32 + li];
-#pragma unroll
-                    for (int i = 0; i < T::kTM; ++i)
-#pragma unroll
-                        for (int j = 0; j < T::kTN; ++j) {
-                            if (ABL == 2) acc[i][j][0] = fmaf(a[i], b[j], acc[i][j][0]);
-                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-                        }
-                }
-                if (more) store_tile(buf ^ 1, was_tail);
-                __syncthreads();
-            }
+            for (int j = 0; j < T::kTN; ++j)
+                b4[g][j] = *reinterpret_cast<const float4*>(&Bs[buf][wn * T::kWTN + j * 32 + li][(g * 8 + lk * 4) ^ (li & 12)]);
         }
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int i = 0; i < T::kTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::kTN; ++j) {
+                        const float av = s4 == 0 ? a4[g][i].x : s4 == 1 ? a4[g][i].y : s4 == 2 ? a4[g][i].z : a4[g][i].w;
+                        const float bv = s4 == 0 ? b4[g][j].x : s4 == 1 ? b4[g][j].y : s4 == 2 ? b4[g][j].z : b4[g][j].w;
+                        if (ABL == 2) acc[i][j][0] = fmaf(av, bv, acc[i][j][0]);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+        if (ABL == 4) {
+            if (more) abl_sink += a_reg[0].x + b_reg0.x + (T::kBIters > 1 ? b_reg1.x : 0.f);
+        } else if (more) {
+            store_tile(buf ^ 1, was_tail);
+        }
+        __syncthreads();
+    };
+    // Pairs of K-tiles run unconditionally (a K-tile under "if (t < T_total)" made hipcc carry the accumulators
+    // in VGPRs and copy all of them to and from the AGPRs around every MFMA block); an odd last tile follows.
+    const int T_pairs = T_total & ~1;
+    for (int t = 0; t < T_pairs; t += 2) {
+        k_tile(0, true);
+        k_tile(1, t + 2 < T_total);
     }
+    if (T_total & 1) k_tile(0, false);
+    if (ABL == 4 && abl_sink == 12345.678f) p.y[0] = abl_sink;
 
     // ---- epilogue ----------------------------------------------------------------------------
     // D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

@@ -106,9 +106,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float
                                                            int Kp, int Np) {
     const long total = (long)taps * Kp * Np;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int n = int(i % Np);
-        const int k = int((i / Np) % Kp);
-        const int t = int(i / ((long)Np * Kp));
+        // packed layout [Kp/16][tap][Np][16] (conv_igemm.h): K-tile major, 16 k contiguous per output channel
+        const int kk = int(i % 16);
+        const int n = int((i / 16) % Np);
+        const int t = int((i / (16l * Np)) % taps);
+        const int k = int(i / (16l * Np * taps)) * 16 + kk;
         wp[i] = (k < Cin && n < Cout) ? w[((long)t * Cin + k) * Cout + n] : 0.f;
     }
 }
@@ -118,9 +120,10 @@ __global__ __launch_bounds__(256) void pack_weights_T_kernel(const float* w, flo
                                                              int KpT, int NpT) {
     const long total = (long)taps * KpT * NpT;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int n = int(i % NpT);
-        const int k = int((i / NpT) % KpT);
-        const int t = int(i / ((long)NpT * KpT));
+        const int kk = int(i % 16);
+        const int n = int((i / 16) % NpT);
+        const int t = int((i / (16l * NpT)) % taps);
+        const int k = int(i / (16l * NpT * taps)) * 16 + kk;
         wpT[i] = (k < Cout && n < Cin) ? w[((long)(taps - 1 - t) * Cin + n) * Cout + k] : 0.f;
     }
 }
@@ -856,8 +859,8 @@ extern "C" int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, 
     std::vector<float> hx(M * x_cs), hw((size_t)taps * (Kp + 32) * Np), hs(Np, 1.0f);
     unsigned st = 12345u;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
-    for (auto& v : hx) v = rnd();
-    for (auto& v : hw) v = rnd() * 0.05f;
+    for (auto& v : hx) v = abl == 6 ? 0.f : rnd();          // abl 6: all-zero operands (DVFS best case)
+    for (auto& v : hw) v = abl == 6 ? 0.f : rnd() * 0.05f;
     rt::h2d(x, hx.data(), hx.size() * sizeof(float), nullptr);
     rt::h2d(wp, hw.data(), hw.size() * sizeof(float), nullptr);
     rt::h2d(sc, hs.data(), hs.size() * sizeof(float), nullptr);
@@ -884,6 +887,13 @@ extern "C" int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, 
             if (abl == 1) DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
             else if (abl == 2) DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
             else DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
+        } else if (abl == 7) {                         // 64x128 tile without refills: LDS reads + MFMA + barriers only
+            dim3 grid(dr_ceil_div(Mi, 64), dr_ceil_div(Np, 128));
+            DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 1>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
+        } else if (abl == 8 || abl == 9) {             // 64x128 tile: refill loads without LDS writes / LDS writes without loads
+            dim3 grid(dr_ceil_div(Mi, 64), dr_ceil_div(Np, 128));
+            if (abl == 8) DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 4>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
+            else DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 5>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
         } else {
             launch_conv_igemm(p, nullptr);
         }

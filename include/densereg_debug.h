@@ -19,7 +19,8 @@ int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, const float* x,
 /* Micro-benchmark one conv shape on self-allocated buffers: average milliseconds per launch.
  * tile = -1 (heuristic) or a tile id (0 128x128, 1 64x128, 2 128x64, 3 64x64, 4 128x32);
  * abl = 0 product kernel, 1/2/3 = ablations of the 128x128 kernel (no refills / no MFMA / no stores),
- * 5 = product kernel with the fused residual add. */
+ * 5 = product kernel with the fused residual add, 6 = product kernel on all-zero operands,
+ * 7 = 64x128 kernel without refills. */
 int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, int tile, int abl, int iters, float* ms_out);
 
 /* Sustained fp32 MFMA TFLOP/s of the device without memory traffic (register-only chains of

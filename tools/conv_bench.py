@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from densereg_amd import _lib  # noqa: E402
 
 TILES = {-1: 'auto', 0: '128x128', 1: '64x128', 2: '128x64', 3: '64x64', 4: '128x32'}
-ABL = {0: '', 1: 'no-refill', 2: 'no-mfma', 3: 'no-store', 5: '+residual'}
+ABL = {0: '', 1: 'no-refill', 2: 'no-mfma', 3: 'no-store', 5: '+residual', 6: 'zero operands', 7: '64x128 no-refill', 8: 'loads, no LDS writes', 9: 'LDS writes, no loads'}
 
 
 def main():
@@ -36,7 +36,7 @@ def main():
         np_ = -(-cout // 32) * 32
         variants = [(-1, 0), (-1, 5)]
         if np_ % 128 == 0:
-            variants += [(0, 0), (1, 0), (0, 1), (0, 2)]
+            variants += [(0, 0), (1, 0), (0, 1), (0, 2), (1, 6), (1, 7), (1, 8), (1, 9)]
         elif np_ % 64 == 0:
             variants += [(2, 0), (3, 0)]
         for tile, abl in variants:

@@ -5,6 +5,7 @@
 // GEMM view per tap: M = Cin, N = Cout, K = B*H*W pixels (the long axis).  Both operands are stored
 // pixel-major with channels contiguous, which is exactly the k-major LDS image the 32x32x2 fp32 MFMA
 // wants (A[i=l&31][k=l>>5] = Xs[pixel k][channel i]): tiles go HBM -> LDS as float4 rows, no transpose.
+// Tensors are addressed with 32-bit element offsets (the host rejects anything larger).
 // The pixel axis is split over `nsplit` workgroups; each writes its partial HWIO tile to a scratch
 // slab and a second kernel folds the slabs into the flat gradient accumulator -- deterministic, no
 // floating-point atomics.  Replaces the Conv2DBackpropFilter ops TF derives for ops.py:282.
@@ -22,16 +23,23 @@ struct WgradParams {
     int nsplit; int rows_per_split;              // multiple of 16
 };
 
-template <int T>   // tile T x T channels, 4 waves as 2 x 2
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+// Tile T x T channels, 4 waves as 2 x 2, wave tile T/2 x T/2.
+// T = 128: a wave owns 64 x 64 = 2 x 2 MFMA tiles.  Which channel an MFMA row/column stands for is free (it only
+// permutes the output), so lane li takes the channel PAIR (2*li, 2*li+1) of its wave's 64 with one ds_read_b64
+// per operand and k-step: MFMA tile t of the pair uses component t, i.e. row i of tile t is channel 2*i + t.
+// That halves the LDS instructions of a dword-per-tile fragment read and reads at 256 B/clk instead of 128.
+// T = 64: one MFMA tile per wave, plain dword reads.
+template <int T>
+__global__ __launch_bounds__(256, (T == 128 ? 3 : 6)) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int BK = 16;                 // pixels per step
     constexpr int ST = T + 4;              // LDS row stride (keeps float4 alignment)
     constexpr int WT = T / 2;              // wave tile
     constexpr int TM = WT / 32;
     constexpr int ITERS = (BK * (T / 4)) / 256;      // float4 loads per thread per operand
-    static_assert(ITERS >= 1, "tile too small for the loader mapping");
-    __shared__ float Xs[2][BK][ST];
-    __shared__ float Gs[2][BK][ST];
+    constexpr int RSTEP = 256 / (T / 4);             // pixel rows between a thread's successive loads
+    static_assert(ITERS >= 1 && 256 % (T / 4) == 0, "tile too small for the loader mapping");
+    __shared__ __attribute__((aligned(16))) float Xs[2][BK][ST];
+    __shared__ __attribute__((aligned(16))) float Gs[2][BK][ST];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -45,44 +53,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int pad = p.ksize / 2;
     const int dy = tap / p.ksize - pad, dx = tap % p.ksize - pad;
     const int HW = p.H * p.W;
-    const long M = (long)p.B * HW;
-    const long m_begin = (long)split * p.rows_per_split;
-    const long m_end = m_begin + p.rows_per_split < M ? m_begin + p.rows_per_split : M;
-    const int steps = m_begin < m_end ? (int)((m_end - m_begin + BK - 1) / BK) : 0;
+    const int M = p.B * HW;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = m_begin + p.rows_per_split < M ? m_begin + p.rows_per_split : M;
+    const int steps = m_begin < m_end ? (m_end - m_begin + BK - 1) / BK : 0;
+    // image sides are powers of two on this network (2..64): shifts instead of divisions in the loader
+    const bool pow2 = (p.W & (p.W - 1)) == 0 && (HW & (HW - 1)) == 0;
+    const int w_shift = __builtin_ctz((unsigned)p.W);
+
+    // ---- loader: everything that does not change from step to step is computed once -------------
+    // A thread always loads the same 4 channels (c4) of pixel rows row0 + i*RSTEP of every step.  Loads are
+    // unconditional (a predicated-off lane reads the tensor base, its value is dropped at store time) and use
+    // 32-bit element offsets; the optional row mask travels with the prefetch instead of gating it.
+    const int c4 = (tid % (T / 4)) * 4;
+    const int row0 = tid / (T / 4);
+    const int gleft = p.Cout - (co0 + c4), xleft = p.Cin - (ci0 + c4);
+    const int g_nvc = gleft < 0 ? 0 : (gleft > 4 ? 4 : gleft);       // valid components of this thread's float4
+    const int x_nvc = xleft < 0 ? 0 : (xleft > 4 ? 4 : xleft);
+    const unsigned g_base = (unsigned)(p.g_coff + co0 + c4), x_base = (unsigned)(p.x_coff + ci0 + c4);
+    const int tap_shift = dy * p.W + dx;
 
     float4 xr[ITERS], gr[ITERS];
+    float xm[ITERS];
     int xnv[ITERS], gnv[ITERS];        // valid leading components of the staged float4 (0 = nothing)
-    // unconditional loads + zero-select at store time (see conv_igemm.h: a branchy load makes hipcc wait right
-    // behind every load and serialises the refill in front of the MFMAs)
-    auto load = [&](int st) {
+    int next_step = 0;
+    auto load = [&]() __attribute__((always_inline)) {
+        const int mb = m_begin + next_step * BK + row0;
+        ++next_step;
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / (T / 4);
-            const int c4 = (idx % (T / 4)) * 4;
-            const long m = m_begin + (long)st * BK + row;
+            const int m = mb + i * RSTEP;
             const bool in_range = m < m_end;
-            // gradient row
-            const int gleft = p.Cout - (co0 + c4);
-            int gv = gleft < 0 ? 0 : (gleft > 4 ? 4 : gleft);
-            if (!in_range) gv = 0;
-            // shifted input row
-            const int xleft = p.Cin - (ci0 + c4);
-            int xv = xleft < 0 ? 0 : (xleft > 4 ? 4 : xleft);
-            long ms = m;
             bool ok = in_range;
             if (p.ksize > 1) {
-                const int rem = (int)((in_range ? m : 0) % HW);
-                const int yy = rem / p.W + dy, xx = rem % p.W + dx;
+                const int mm = in_range ? m : 0;
+                int yy, xx;
+                if (pow2) {
+                    const int rem = mm & (HW - 1);
+                    yy = (rem >> w_shift) + dy; xx = (rem & (p.W - 1)) + dx;
+                } else {
+                    const int rem = mm % HW;
+                    yy = rem / p.W + dy; xx = rem % p.W + dx;
+                }
                 ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-                ms = m + (long)dy * p.W + dx;
             }
-            if (!ok) { xv = 0; ms = 0; }
-            if (p.rowmask && xv && p.rowmask[ms] < p.mask_thresh) xv = 0;
-            const float* gsrc = gv ? p.g + m * p.g_cs + p.g_coff + co0 + c4 : p.g;
-            const float* xsrc = xv ? p.x + ms * p.x_cs + p.x_coff + ci0 + c4 : p.x;
-            gr[i] = *reinterpret_cast<const float4*>(gsrc);
-            xr[i] = *reinterpret_cast<const float4*>(xsrc);
+            const unsigned ms = ok ? (unsigned)(m + tap_shift) : 0u;
+            const int gv = in_range ? g_nvc : 0, xv = ok ? x_nvc : 0;
+            gr[i] = *reinterpret_cast<const float4*>(gv ? p.g + ((unsigned)m * (unsigned)p.g_cs + g_base) : p.g);
+            xr[i] = *reinterpret_cast<const float4*>(xv ? p.x + (ms * (unsigned)p.x_cs + x_base) : p.x);
+            if (p.rowmask) xm[i] = p.rowmask[ms];
             gnv[i] = gv;
             xnv[i] = xv;
         }
@@ -90,13 +109,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     auto zsel = [](float4 v, int nv) {
         return make_float4(nv > 0 ? v.x : 0.f, nv > 1 ? v.y : 0.f, nv > 2 ? v.z : 0.f, nv > 3 ? v.w : 0.f);
     };
-    auto store = [&](int buf) {
+    auto store = [&](const int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / (T / 4);
-            const int c4 = (idx % (T / 4)) * 4;
-            *reinterpret_cast<float4*>(&Xs[buf][row][c4]) = zsel(xr[i], xnv[i]);
+            const int row = row0 + i * RSTEP;
+            const int xv = (p.rowmask && xm[i] < p.mask_thresh) ? 0 : xnv[i];
+            *reinterpret_cast<float4*>(&Xs[buf][row][c4]) = zsel(xr[i], xv);
             *reinterpret_cast<float4*>(&Gs[buf][row][c4]) = zsel(gr[i], gnv[i]);
         }
     };
@@ -110,40 +128,60 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (steps > 0) {
-        load(0);
+        load();
         store(0);
     }
     __syncthreads();
-    for (int st = 0; st < steps; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < steps) load(st + 1);
+    // one step of 16 pixels from LDS buffer `buf` (a compile-time constant: the loop below is unrolled by two)
+    auto k_step = [&](const int buf, const bool more) __attribute__((always_inline)) {
+        if (more) load();
+        if constexpr (TM == 2) {
+            float2 a2[BK / 2], b2[BK / 2];                       // every fragment of the step, read up front
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], b[TM];
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                a2[kk] = *reinterpret_cast<const float2*>(&Xs[buf][2 * kk + lk][wm * WT + 2 * li]);
+                b2[kk] = *reinterpret_cast<const float2*>(&Gs[buf][2 * kk + lk][wn * WT + 2 * li]);
+            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Xs[buf][2 * kk + lk][wm * WT + i * 32 + li];
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk].x, b2[kk].x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk].x, b2[kk].y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk].y, b2[kk].x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk].y, b2[kk].y, acc[1][1], 0, 0, 0);
+            }
+        } else {
+            float a[BK / 2], b[BK / 2];
 #pragma unroll
-            for (int j = 0; j < TM; ++j) b[j] = Gs[buf][2 * kk + lk][wn * WT + j * 32 + li];
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                a[kk] = Xs[buf][2 * kk + lk][wm * WT + li];
+                b[kk] = Gs[buf][2 * kk + lk][wn * WT + li];
+            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int kk = 0; kk < BK / 2; ++kk)
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc[0][0], 0, 0, 0);
         }
-        if (st + 1 < steps) store(buf ^ 1);
+        if (more) store(buf ^ 1);
         __syncthreads();
+    };
+    const int pairs = steps & ~1;
+    for (int st = 0; st < pairs; st += 2) {
+        k_step(0, true);
+        k_step(1, st + 2 < steps);
     }
+    if (steps & 1) k_step(0, false);
 
-    // partial[split][tap][ci][co]; D: row(ci) = (r&3)+8*(r>>2)+4*lk, col(co) = li
+    // partial[split][tap][ci][co]; D: row = (r&3)+8*(r>>2)+4*lk, col = li; with TM = 2 row/col i of tile t is
+    // channel 2*i + t of the wave's 64 (see above), with TM = 1 it is channel i.
     float* dst = p.partial + ((long)split * taps + tap) * p.Cin * p.Cout;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int co = co0 + wn * WT + j * 32 + li;
+        const int co = co0 + wn * WT + (TM == 2 ? 2 * li + j : li);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ci = ci0 + wm * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int ci = ci0 + wm * WT + (TM == 2 ? 2 * row + i : row);
                 if (ci < p.Cin && co < p.Cout) dst[(long)ci * p.Cout + co] = acc[i][j][r];
             }
     }

@@ -843,6 +843,34 @@ extern "C" int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, cons
     return DR_OK;
 }
 
+// Weight gradient of one conv on caller buffers: dw[k][k][Cin][Cout] = sum_pixels x(shifted) * g.  T = 64 / 128
+// picks the tile, nsplit the number of pixel-axis slabs (folded by wgrad_reduce_kernel), as the executor does.
+extern "C" int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const float* x, int x_cs, const float* g, int g_cs,
+                            const float* rowmask, float thresh, int T, int nsplit, float* dw, dr_stream stream) {
+    if (!x || !g || !dw || (k != 1 && k != 3) || (T != 64 && T != 128) || nsplit < 1) return DR_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int taps = k * k;
+    const long M = (long)B * H * W;
+    const size_t per = (size_t)taps * Cin * Cout;
+    const int rows = dr_round_up((int)((M + nsplit - 1) / nsplit), 16);
+    nsplit = (int)((M + rows - 1) / rows);
+    float* partial = (float*)rt::dmalloc((size_t)nsplit * per * sizeof(float));
+    if (!partial) return DR_E_NOMEM;
+    WgradParams p{};
+    p.x = x; p.x_cs = x_cs; p.Cin = Cin; p.g = g; p.g_cs = g_cs; p.Cout = Cout;
+    p.B = B; p.H = H; p.W = W; p.ksize = k; p.rowmask = rowmask; p.mask_thresh = thresh;
+    p.partial = partial; p.nsplit = nsplit; p.rows_per_split = rows;
+    dim3 grid(dr_ceil_div(Cin, T) * dr_ceil_div(Cout, T), taps, nsplit);
+    if (T == 128) DR_LAUNCH((conv_wgrad_kernel<128>), grid, dim3(256), 0, s, p);
+    else DR_LAUNCH((conv_wgrad_kernel<64>), grid, dim3(256), 0, s, p);
+    rt::memset_async(dw, 0, per * sizeof(float), s);
+    DR_LAUNCH(wgrad_reduce_kernel, dim3(grid_for((long)per, 64)), dim3(256), 0, s, (const float*)partial, nsplit, (long)per, dw);
+    rt::sync_stream(s);
+    rt::dfree(partial);
+    std::string m;
+    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
+}
+
 // Micro-benchmark of one conv shape: allocates its own buffers, `iters` launches timed with events.
 // tile: -1 heuristic, else a KernelId of a conv tile; abl: ablation variant of the 128x128 kernel.
 extern "C" int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, int tile, int abl, int iters, float* ms_out) {

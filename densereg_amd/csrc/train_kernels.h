@@ -41,23 +41,32 @@ struct BnTrainParams {
     View res, out;
 };
 
+// Streaming kernels below keep kBnRows independent 16-byte loads per thread and stream in flight: hipcc does
+// not batch the loads of a "#pragma unroll"-ed grid-stride loop by itself (it waited for each one), which held
+// these passes at ~3 TB/s of the ~8 TB/s HBM.
+constexpr int kBnRows = 4;
+
 __device__ __forceinline__ void bn_channel_coeffs(const BnTrainParams& p, int c, float& sc_out, float& sh_out, bool persist) {
+    // every global read first (independent, one round trip), then the arithmetic, then the stores
+    const double sum = p.sum[c], sq = p.sq[c];
+    const float mm = p.mm[c], mv = p.mv[c], g = p.gamma[c], beta = p.beta[c];
+    float sh_m = 0.f, sh_v = 0.f;
+    if (persist && p.shadow_step > 0) { sh_m = p.shadow_mean[c]; sh_v = p.shadow_var[c]; }
     const double cnt = (double)p.M;
-    const double mean_d = p.sum[c] / cnt;
-    double var_d = p.sq[c] / cnt - mean_d * mean_d;
+    const double mean_d = sum / cnt;
+    double var_d = sq / cnt - mean_d * mean_d;
     if (var_d < 0.0) var_d = 0.0;
     const float mean = (float)mean_d, var = (float)var_d;
     const float std_b = sqrtf(var + p.eps);
     const float inv_std = 1.0f / std_b;
-    const float mstd = sqrtf(p.mv[c] + p.eps);
+    const float mstd = sqrtf(mv + p.eps);
     float r = std_b / mstd;
     r = fminf(fmaxf(r, 1.0f / p.r_max), p.r_max);
-    float d = (mean - p.mm[c]) / mstd;
+    float d = (mean - mm) / mstd;
     d = fminf(fmaxf(d, -p.d_max), p.d_max);
-    const float g = p.gamma[c];
     const float sc = inv_std * r;
     sc_out = sc * g;
-    sh_out = (d - mean * sc) * g + p.beta[c];
+    sh_out = (d - mean * sc) * g + beta;
     if (persist) {
         p.scale[c] = sc_out;
         p.shift[c] = sh_out;
@@ -67,61 +76,79 @@ __device__ __forceinline__ void bn_channel_coeffs(const BnTrainParams& p, int c,
         p.bnc[3 * p.C + c] = d;
         const float om = 1.0f - p.decay;
         if (p.shadow_step > 0) {
-            const float bm = p.shadow_mean[c] - (p.shadow_mean[c] - mean) * om;
-            const float bv = p.shadow_var[c] - (p.shadow_var[c] - var) * om;
+            const float bm = sh_m - (sh_m - mean) * om;
+            const float bv = sh_v - (sh_v - var) * om;
             p.shadow_mean[c] = bm;
             p.shadow_var[c] = bv;
             const float corr = 1.0f - powf(p.decay, (float)p.shadow_step);
             p.mm_next[c] = bm / corr;
             p.mv_next[c] = bv / corr;
         } else {
-            p.mm_next[c] = p.mm[c] - (p.mm[c] - mean) * om;
-            p.mv_next[c] = p.mv[c] - (p.mv[c] - var) * om;
+            p.mm_next[c] = mm - (mm - mean) * om;
+            p.mv_next[c] = mv - (mv - var) * om;
         }
     }
 }
 
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams p) {
-    const int c4n = p.raw_cs / 4;                  // channel groups per row (<= 128 on this network)
+    // scale/shift of every channel once per workgroup (one channel per thread), shared through LDS
+    __shared__ float s_sc[1024], s_sh[1024];
+    for (int c = threadIdx.x; c < p.raw_cs; c += 256) {
+        float sc = 0.f, sh = 0.f;
+        if (c < p.C) bn_channel_coeffs(p, c, sc, sh, blockIdx.x == 0);
+        s_sc[c] = sc; s_sh[c] = sh;
+    }
+    __syncthreads();
+    const int c4n = p.raw_cs / 4;                  // channel groups per row (<= 256)
     const int rpb = 256 / c4n;                     // rows per workgroup pass
     const int cg = threadIdx.x % c4n, rp = threadIdx.x / c4n;
     if (rp >= rpb) return;
     float sc[4], sh[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = cg * 4 + k;
-        sc[k] = 0.f; sh[k] = 0.f;
-        if (c < p.C) bn_channel_coeffs(p, c, sc[k], sh[k], blockIdx.x == 0 && rp == 0);
-    }
+    for (int k = 0; k < 4; ++k) { sc[k] = s_sc[cg * 4 + k]; sh[k] = s_sh[cg * 4 + k]; }
     const bool full = cg * 4 + 4 <= p.C;
     const bool vec_out = full && (p.out.coff % 4 == 0) && (p.out.cs % 4 == 0);
-    const bool vec_res = p.res.p && (p.res.coff % 4 == 0) && (p.res.cs % 4 == 0);
-#pragma unroll 4
-    for (long m = (long)blockIdx.x * rpb + rp; m < p.M; m += (long)gridDim.x * rpb) {
-        const float4 x = *reinterpret_cast<const float4*>(p.raw + m * p.raw_cs + cg * 4);
-        float v[4] = {x.x * sc[0] + sh[0], x.y * sc[1] + sh[1], x.z * sc[2] + sh[2], x.w * sc[3] + sh[3]};
-        if (p.relu) {
+    const bool vec_res = p.res.p && full && (p.res.coff % 4 == 0) && (p.res.cs % 4 == 0);
+    const long stride = (long)gridDim.x * rpb;
+    for (long m0 = (long)blockIdx.x * rpb + rp; m0 < p.M; m0 += stride * kBnRows) {
+        float4 x[kBnRows], rv[kBnRows];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        for (int u = 0; u < kBnRows; ++u) {
+            const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;     // tail rows re-read the last row
+            x[u] = *reinterpret_cast<const float4*>(p.raw + mc * p.raw_cs + cg * 4);
         }
-        if (p.res.p) {
-            const float* rs = p.res.p + m * p.res.cs + p.res.coff + cg * 4;
-            if (vec_res && full) {
-                const float4 rv = *reinterpret_cast<const float4*>(rs);
-                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-            } else {
+        if (vec_res) {
+#pragma unroll
+            for (int u = 0; u < kBnRows; ++u) {
+                const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
+                rv[u] = *reinterpret_cast<const float4*>(p.res.p + mc * p.res.cs + p.res.coff + cg * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kBnRows; ++u) {
+            const long m = m0 + u * stride;
+            if (m >= p.M) break;
+            float v[4] = {x[u].x * sc[0] + sh[0], x[u].y * sc[1] + sh[1], x[u].z * sc[2] + sh[2], x[u].w * sc[3] + sh[3]};
+            if (p.relu) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+            if (vec_res) {
+                v[0] += rv[u].x; v[1] += rv[u].y; v[2] += rv[u].z; v[3] += rv[u].w;
+            } else if (p.res.p) {
+                const float* rs = p.res.p + m * p.res.cs + p.res.coff + cg * 4;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (cg * 4 + k < p.C) v[k] += rs[k];
             }
-        }
-        float* o = p.out.p + m * p.out.cs + p.out.coff + cg * 4;
-        if (vec_out) {
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
+            float* o = p.out.p + m * p.out.cs + p.out.coff + cg * 4;
+            if (vec_out) {
+                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (cg * 4 + k < p.C) o[k] = v[k];
+                for (int k = 0; k < 4; ++k)
+                    if (cg * 4 + k < p.C) o[k] = v[k];
+            }
         }
     }
 }
@@ -162,26 +189,42 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
         }
         const bool full = cg * 4 + 4 <= p.C;
         const bool vec_d = full && (p.dout.coff % 4 == 0) && (p.dout.cs % 4 == 0);
-    #pragma unroll 4
-    for (long m = (long)blockIdx.x * rpb + rp; m < p.M; m += (long)gridDim.x * rpb) {
-            const float4 x4 = *reinterpret_cast<const float4*>(p.raw + m * p.raw_cs + cg * 4);
-            const float x[4] = {x4.x, x4.y, x4.z, x4.w};
-            float g[4] = {0.f, 0.f, 0.f, 0.f};
-            const float* dp = p.dout.p + m * p.dout.cs + p.dout.coff + cg * 4;
-            if (vec_d) {
-                const float4 d4 = *reinterpret_cast<const float4*>(dp);
-                g[0] = d4.x; g[1] = d4.y; g[2] = d4.z; g[3] = d4.w;
-            } else {
+        const long stride = (long)gridDim.x * rpb;
+        for (long m0 = (long)blockIdx.x * rpb + rp; m0 < p.M; m0 += stride * kBnRows) {
+            float4 x4[kBnRows], d4[kBnRows];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (cg * 4 + k < p.C) g[k] = dp[k];
+            for (int u = 0; u < kBnRows; ++u) {
+                const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
+                x4[u] = *reinterpret_cast<const float4*>(p.raw + mc * p.raw_cs + cg * 4);
+            }
+            if (vec_d) {
+#pragma unroll
+                for (int u = 0; u < kBnRows; ++u) {
+                    const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
+                    d4[u] = *reinterpret_cast<const float4*>(p.dout.p + mc * p.dout.cs + p.dout.coff + cg * 4);
+                }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (p.relu && !(x[k] * sc[k] + sh[k] > 0.f)) g[k] = 0.f;
-                const float yh = (x[k] - mean[k]) * istd[k];
-                a[k] += (double)g[k];
-                b[k] += (double)g[k] * (double)yh;
+            for (int u = 0; u < kBnRows; ++u) {
+                const long m = m0 + u * stride;
+                if (m >= p.M) break;
+                const float x[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};
+                float g[4] = {0.f, 0.f, 0.f, 0.f};
+                if (vec_d) {
+                    g[0] = d4[u].x; g[1] = d4[u].y; g[2] = d4[u].z; g[3] = d4[u].w;
+                } else {
+                    const float* dp = p.dout.p + m * p.dout.cs + p.dout.coff + cg * 4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (cg * 4 + k < p.C) g[k] = dp[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (p.relu && !(x[k] * sc[k] + sh[k] > 0.f)) g[k] = 0.f;
+                    const float yh = (x[k] - mean[k]) * istd[k];
+                    a[k] += (double)g[k];
+                    b[k] += (double)g[k] * (double)yh;
+                }
             }
         }
     }
@@ -227,28 +270,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
     }
     const bool full = cg * 4 + 4 <= p.C;
     const bool vec_d = full && (p.dout.coff % 4 == 0) && (p.dout.cs % 4 == 0);
-#pragma unroll 4
-    for (long m = (long)blockIdx.x * rpb + rp; m < p.M; m += (long)gridDim.x * rpb) {
-        const float4 x4 = *reinterpret_cast<const float4*>(p.raw + m * p.raw_cs + cg * 4);
-        const float x[4] = {x4.x, x4.y, x4.z, x4.w};
-        float g[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* dp = p.dout.p + m * p.dout.cs + p.dout.coff + cg * 4;
+    const long stride = (long)gridDim.x * rpb;
+    for (long m0 = (long)blockIdx.x * rpb + rp; m0 < p.M; m0 += stride * kBnRows) {
+        float4 x4[kBnRows], d4[kBnRows];
+#pragma unroll
+        for (int u = 0; u < kBnRows; ++u) {
+            const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
+            x4[u] = *reinterpret_cast<const float4*>(p.raw + mc * p.raw_cs + cg * 4);
+        }
         if (vec_d) {
-            const float4 d4 = *reinterpret_cast<const float4*>(dp);
-            g[0] = d4.x; g[1] = d4.y; g[2] = d4.z; g[3] = d4.w;
-        } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (cg * 4 + k < p.C) g[k] = dp[k];
+            for (int u = 0; u < kBnRows; ++u) {
+                const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
+                d4[u] = *reinterpret_cast<const float4*>(p.dout.p + mc * p.dout.cs + p.dout.coff + cg * 4);
+            }
         }
-        float o[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (p.relu && !(x[k] * sc[k] + sh[k] > 0.f)) g[k] = 0.f;
-            const float yh = (x[k] - mean[k]) * istd[k];
-            o[k] = (cg * 4 + k < p.C) ? c1[k] * (g[k] - c2[k] - yh * c3[k]) : 0.f;
+        for (int u = 0; u < kBnRows; ++u) {
+            const long m = m0 + u * stride;
+            if (m >= p.M) break;
+            const float x[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+            if (vec_d) {
+                g[0] = d4[u].x; g[1] = d4[u].y; g[2] = d4[u].z; g[3] = d4[u].w;
+            } else {
+                const float* dp = p.dout.p + m * p.dout.cs + p.dout.coff + cg * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (cg * 4 + k < p.C) g[k] = dp[k];
+            }
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (p.relu && !(x[k] * sc[k] + sh[k] > 0.f)) g[k] = 0.f;
+                const float yh = (x[k] - mean[k]) * istd[k];
+                o[k] = (cg * 4 + k < p.C) ? c1[k] * (g[k] - c2[k] - yh * c3[k]) : 0.f;
+            }
+            *reinterpret_cast<float4*>(p.draw + m * p.raw_cs + cg * 4) = make_float4(o[0], o[1], o[2], o[3]);
         }
-        *reinterpret_cast<float4*>(p.draw + m * p.raw_cs + cg * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 

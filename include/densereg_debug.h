@@ -16,6 +16,12 @@ int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, const float* x,
                   const float* scale, const float* shift, int relu, const float* res, int res_cs,
                   const float* rowmask, float thresh, float* y, int y_cs, double* stat, dr_stream stream);
 
+/* Weight gradient of one conv on caller buffers (device pointers, NHWC with row strides x_cs / g_cs):
+ * dw[k][k][Cin][Cout] = sum over pixels of x(shifted by the tap, zero outside the image or where
+ * rowmask[pixel] < thresh) * g.  T = 64 or 128 picks the channel tile, nsplit the pixel-axis slabs. */
+int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const float* x, int x_cs, const float* g, int g_cs,
+                 const float* rowmask, float thresh, int T, int nsplit, float* dw, dr_stream stream);
+
 /* Micro-benchmark one conv shape on self-allocated buffers: average milliseconds per launch.
  * tile = -1 (heuristic) or a tile id (0 128x128, 1 64x128, 2 128x64, 3 64x64, 4 128x32);
  * abl = 0 product kernel, 1/2/3 = ablations of the 128x128 kernel (no refills / no MFMA / no stores),

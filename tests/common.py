@@ -67,6 +67,23 @@ class Backend:
         y = yp[..., :Cout].copy()
         return (y, self.host(d_st)) if want_stats else y
 
+    def wgrad(self, x, g, k, T, nsplit, rowmask=None, thresh=0.0):
+        B, H, W, Cin = x.shape
+        Cout = g.shape[-1]
+        x_cs, g_cs = -(-Cin // 4) * 4 + 4, -(-Cout // 4) * 4
+        xp = np.full((B, H, W, x_cs), np.nan, np.float32)       # pad channels are poison: must not reach the result
+        xp[..., :Cin] = x
+        gp = np.full((B, H, W, g_cs), np.nan, np.float32)
+        gp[..., :Cout] = g
+        d_x, d_g = self.dev(xp), self.dev(gp)
+        d_m = None if rowmask is None else self.dev(rowmask)
+        d_w = self.dev(np.full((k, k, Cin, Cout), -777.0, np.float32))
+        rc = self.lib.dr_dbg_wgrad(B, H, W, Cin, Cout, k, self.ptr(d_x), x_cs, self.ptr(d_g), g_cs, self.ptr(d_m), thresh,
+                                   T, nsplit, self.ptr(d_w), self.stream)
+        assert rc == 0, rc
+        self.sync()
+        return self.host(d_w)
+
     def forward_eval(self, h, ndm):
         B, J, m = ndm.shape[0], h.cfg.num_jnt, h.cfg.in_hw // 4
         d_dm = self.dev(ndm)

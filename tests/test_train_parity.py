@@ -110,6 +110,38 @@ def test_train_step_config3_nyu_two_stacks_dropout_mask(gpu):
     h.close()
 
 
+WGRAD_CASES = [
+    # B, H, W, Cin, Cout, k, T, nsplit, masked
+    (2, 8, 8, 64, 64, 3, 64, 3, False),
+    (1, 16, 16, 128, 128, 1, 128, 4, False),
+    (2, 8, 8, 130, 70, 3, 128, 2, True),        # ragged channels on both sides, two ci tiles, row mask
+    (1, 9, 7, 37, 45, 3, 64, 2, False),         # non power-of-two image: the division path of the loader
+    (3, 4, 4, 200, 131, 1, 128, 1, True),
+    (1, 2, 2, 64, 64, 3, 64, 1, False),         # image smaller than one 16-pixel step
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_CASES, ids=lambda c: 'x'.join(str(int(v)) for v in c))
+def test_wgrad_kernel_direct(be, case):
+    """conv_wgrad_kernel (both channel tiles) against an fp64 einsum of the definition."""
+    B, H, W, Cin, Cout, k, T, nsplit, masked = case
+    rng = np.random.default_rng(sum(case[:6]))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    g = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
+    mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if masked else None
+    dw = be.wgrad(x, g, k, T, nsplit, mask, -0.25)
+    xz = x.astype(np.float64)
+    if masked:
+        xz = xz * (~(mask.reshape(B, H, W, 1) < -0.25))
+    pad = k // 2
+    xp = np.pad(xz, ((0, 0), (pad, pad), (pad, pad), (0, 0)))
+    ref = np.zeros((k, k, Cin, Cout))
+    for dy in range(k):
+        for dx in range(k):
+            ref[dy, dx] = np.einsum('bhwc,bhwd->cd', xp[:, dy:dy + H, dx:dx + W], g.astype(np.float64))
+    assert np.abs(dw - ref).max() / np.abs(ref).max() < 2e-5
+
+
 def test_adam_clip_accumulate_kernel(be):
     """Feed IDENTICAL gradients to the engine's fused clip+Adam and to the oracle (two steps)."""
     from oracle import net, train

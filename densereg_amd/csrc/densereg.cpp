@@ -81,6 +81,19 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     return 0;
 }
 
+// stream of an executor lane: the caller's stream for lane 0, or when lanes are disabled / profiling
+static inline hipStream_t lane_of(const dr_handle* h, int lane, hipStream_t main) {
+    return (lane == 0 || !h->multi_stream || h->profiling) ? main : h->lane_stream[lane];
+}
+// event edge `from` -> `to`: everything enqueued on `from` so far happens before what follows on `to`
+static inline void lane_edge(dr_handle* h, const Op& op, bool parent_to_child, hipStream_t main) {
+    hipStream_t a = lane_of(h, op.lane, main), b = lane_of(h, op.lane2, main);
+    if (a == b) return;
+    if (!parent_to_child) std::swap(a, b);
+    rt::event_record(h->lane_ev[op.ev], a);
+    rt::stream_wait_event(b, h->lane_ev[op.ev]);
+}
+
 // RAII profiling scope: two events around the launches of one op (only when profiling is on)
 struct ProfScope {
     dr_handle* h; hipStream_t s; ProfRecord r;
@@ -148,6 +161,7 @@ struct Builder {
     dr_handle* h;
     int stem_count = 0, root_count = 0;
     bool in_stem = false;
+    int cur_lane = 0;                  // lane of the ops being appended (net.h: executor lanes)
 
     Tensor* new_tensor(int H, int W, int C, const char* tag) {
         auto t = std::make_unique<Tensor>();
@@ -181,6 +195,7 @@ struct Builder {
         Op op;
         op.kind = h->convs[ci].k == 7 ? OP_STEM : OP_CONV;
         op.in = in; op.out = out; op.in2 = res; op.conv = ci; op.masked = masked; op.dropout = dropout;
+        op.lane = cur_lane;
         h->ops.push_back(op);
     }
 
@@ -213,26 +228,43 @@ struct Builder {
     TView pool(TView in, int k) {
         const int Ho = (in.t->H + 1) / 2, Wo = (in.t->W + 1) / 2;
         TView out = whole(new_tensor(Ho, Wo, in.C, "pool"));
-        Op op; op.kind = OP_POOL; op.in = in; op.out = out; op.pool_k = k;
+        Op op; op.kind = OP_POOL; op.in = in; op.out = out; op.pool_k = k; op.lane = cur_lane;
         h->ops.push_back(op);
         return out;
     }
 
-    // um_v1.py:51-69
+    void edge(OpKind kind, int parent, int child) {
+        Op op; op.kind = kind; op.lane = parent; op.lane2 = child; op.ev = (int)h->lane_ev.size();
+        h->lane_ev.push_back(rt::event_create_sync());
+        h->ops.push_back(op);
+    }
+
+    // um_v1.py:51-69.  Variables (conv names) are created in the reference's order: upper residual, lower
+    // residual, inner hourglass, last residual.  The OPS are emitted pool-first so that the fork sits in front of
+    // both branches: the upper residual runs on this level's lane, the pooled pyramid on the next lane.  Only this
+    // lane touches grad(ins) in the reverse sweep (upper residual, then -- after the child lane joined -- the pool).
     TView hourglass(TView ins, int n, TView dst = TView()) {
-        TView upper1 = residual(ins, 0);
+        const int parent = cur_lane;
+        const int child = std::min(parent + 1, DR_MAX_LANES - 1);
+        const bool split = child != parent;
         TView lower1 = pool(ins, h->cfg.kernel_size);
+        if (split) edge(OP_FORK, parent, child);
+        TView upper1 = residual(ins, 0);
+        cur_lane = child;
         lower1 = residual(lower1, 0);
         TView lower2 = n > 1 ? hourglass(lower1, n - 1) : lower1;
         TView lower3 = residual(lower2, 0);
+        cur_lane = parent;
+        if (split) edge(OP_JOIN, parent, child);
+        h->n_lanes = std::max(h->n_lanes, child + 1);
         if (!dst.valid()) dst = whole(new_tensor(ins.t->H, ins.t->W, ins.C, "hg.out"));
-        Op op; op.kind = OP_UPADD; op.in = upper1; op.in2 = lower3; op.out = dst;
+        Op op; op.kind = OP_UPADD; op.in = upper1; op.in2 = lower3; op.out = dst; op.lane = parent;
         h->ops.push_back(op);
         return dst;
     }
 
     void copy(TView src, TView dst) {
-        Op op; op.kind = OP_COPY; op.in = src; op.out = dst;
+        Op op; op.kind = OP_COPY; op.in = src; op.out = dst; op.lane = cur_lane;
         h->ops.push_back(op);
     }
 
@@ -337,6 +369,12 @@ static void free_all(dr_handle* h) {
                     (void*)h->act_arena, (void*)h->grad_arena, (void*)h->scratch, (void*)h->tiny, (void*)h->tiny_ext, (void*)h->zeros,
                     (void*)h->losses, (void*)h->reg_segs, (void*)h->loss_acc, (void*)h->bn_coef, (void*)h->wg_partial})
         if (p) rt::dfree(p);
+    for (int l = 1; l < DR_MAX_LANES; ++l) {
+        if (h->scratch_l[l]) rt::dfree(h->scratch_l[l]);
+        if (h->wg_partial_l[l]) rt::dfree(h->wg_partial_l[l]);
+        rt::stream_destroy(h->lane_stream[l]);
+    }
+    for (auto& e : h->lane_ev) rt::event_destroy(e);
 }
 
 namespace {
@@ -430,6 +468,15 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
     alloc_f(h->fold, nfold);
     alloc_f(h->act_arena, h->n_act);
     alloc_f(h->scratch, h->n_scratch);
+    h->scratch_l[0] = h->scratch;
+    {
+        const char* single = getenv("DR_SINGLE_STREAM");
+        h->multi_stream = !(single && single[0] == '1');
+    }
+    for (int l = 1; l < h->n_lanes; ++l) {
+        h->lane_stream[l] = rt::stream_create();
+        if (cfg->training) alloc_f(h->scratch_l[l], h->n_scratch);         // 288 GB of HBM: no need to be clever
+    }
     alloc_f(h->tiny, MB * h->map_hw * h->map_hw);
     alloc_f(h->tiny_ext, MB * h->map_hw * h->map_hw);
     alloc_f(h->losses, 4);
@@ -708,8 +755,10 @@ static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s
         h->fold_is_eval = true;
     }
     for (const Op& op : h->ops) {
+        if (op.kind == OP_FORK || op.kind == OP_JOIN) { lane_edge(h, op, op.kind == OP_FORK, s); continue; }
         h->prof_tag = op.conv;
-        int rc = (op.kind == OP_CONV || op.kind == OP_STEM) ? run_conv_eval(h, op, B, s) : run_simple_op(h, op, B, s);
+        hipStream_t ls = lane_of(h, op.lane, s);
+        int rc = (op.kind == OP_CONV || op.kind == OP_STEM) ? run_conv_eval(h, op, B, ls) : run_simple_op(h, op, B, ls);
         if (rc) return rc;
     }
     h->prof_tag = -1;

@@ -34,6 +34,10 @@ inline Event event_create() { return Event{0}; }
 inline void event_destroy(Event) {}
 inline void event_record(Event, hipStream_t) {}
 inline float event_elapsed_ms(Event, Event) { return 0.f; }
+inline Event event_create_sync() { return Event{0}; }
+inline hipStream_t stream_create() { return (hipStream_t) nullptr; }         // the emulator runs every launch synchronously
+inline void stream_destroy(hipStream_t) {}
+inline void stream_wait_event(hipStream_t, Event) {}
 }}  // namespace dr::rt
 #else
 // ---------------------------------------------------------------------------------------------
@@ -65,6 +69,11 @@ inline Event event_create() { Event ev{}; (void)hipEventCreate(&ev.e); return ev
 inline void event_destroy(Event ev) { (void)hipEventDestroy(ev.e); }
 inline void event_record(Event ev, hipStream_t s) { (void)hipEventRecord(ev.e, s); }
 inline float event_elapsed_ms(Event a, Event b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, a.e, b.e); return ms; }
+// ordering-only event (no timestamps) and the library-owned side streams of the executor's lanes
+inline Event event_create_sync() { Event ev{}; (void)hipEventCreateWithFlags(&ev.e, hipEventDisableTiming); return ev; }
+inline hipStream_t stream_create() { hipStream_t s = nullptr; (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking); return s; }
+inline void stream_destroy(hipStream_t s) { if (s) (void)hipStreamDestroy(s); }
+inline void stream_wait_event(hipStream_t s, Event ev) { (void)hipStreamWaitEvent(s, ev.e, 0); }
 }}  // namespace dr::rt
 #endif
 

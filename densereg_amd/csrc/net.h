@@ -54,7 +54,14 @@ struct ConvLayer {
     Tensor* raw = nullptr;             // pre-BN conv output (training)
 };
 
-enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_UPADD, OP_UVD, OP_COPY };
+enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_UPADD, OP_UVD, OP_COPY, OP_FORK, OP_JOIN };
+
+// Executor lanes.  The two branches of an hourglass level (um_v1.py:51-69: the residual at this resolution and
+// the pooled pyramid below it) are independent until their upsample-add, and everything below 32x32 is a chain of
+// tiny, latency-bound launches.  The graph builder puts hourglass depth d on lane d and its lower pyramid on lane
+// d+1; lane 0 is the caller's stream, lanes >= 1 are library-owned HIP streams.  OP_FORK (parent -> child) and
+// OP_JOIN (child -> parent) are event edges; the reverse sweep of the backward pass swaps their roles.
+constexpr int DR_MAX_LANES = 8;
 
 struct Op {
     OpKind kind;
@@ -63,6 +70,9 @@ struct Op {
     bool masked = false;               // depth mask on the input rows (um_v1.py:146-148)
     int dropout = -1;                  // dropout slot index (stack*2 + i) or -1
     int pool_k = 0;
+    int lane = 0;                      // stream lane the op runs on (FORK/JOIN: the parent lane)
+    int lane2 = 0;                     // FORK/JOIN: the child lane
+    int ev = -1;                       // FORK/JOIN: index into dr_handle::lane_ev
     TView uvd0, uvd1;                  // OP_UVD destinations
     bool ow_in = false, ow_in2 = false; // backward: this op is the FIRST writer of grad(in) / grad(in2) -> overwrite
 };
@@ -115,6 +125,11 @@ struct dr_handle {
     float* act_arena = nullptr;  size_t n_act = 0;
     float* grad_arena = nullptr; size_t n_gact = 0;
     float* scratch = nullptr;    size_t n_scratch = 0;     // dRaw scratch (training) / dense copies
+    float* scratch_l[dr::DR_MAX_LANES] = {};                // one per lane (index 0 aliases `scratch`)
+    hipStream_t lane_stream[dr::DR_MAX_LANES] = {};         // [0] unused: lane 0 is the caller's stream
+    std::vector<dr::rt::Event> lane_ev;                     // one ordering event per FORK / JOIN op
+    int n_lanes = 1;
+    bool multi_stream = true;                              // DR_SINGLE_STREAM=1 or profiling: every lane = caller's stream
     float* tiny = nullptr;                                  // (B,h,w) normalised depth at map resolution
     float* tiny_ext = nullptr;                              // same, for dr_vote on external maps
     float* zeros = nullptr;                                 // 256 B of zeros: target of predicated-off loads
@@ -137,6 +152,7 @@ struct dr_handle {
     double* loss_acc = nullptr;                            // 4 doubles: hm, hm3, um, reg
     float* bn_coef = nullptr;                              // 3*max(cout) floats (BatchReNorm backward)
     float* wg_partial = nullptr; size_t n_wg_partial = 0;  // split-K slabs of the weight gradient
+    float* wg_partial_l[dr::DR_MAX_LANES] = {};             // one per lane (index 0 aliases `wg_partial`)
     bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold
     const float* dm_train = nullptr;                       // input of the last dr_forward_train
 };

@@ -110,6 +110,46 @@ def test_train_step_config3_nyu_two_stacks_dropout_mask(gpu):
     h.close()
 
 
+@pytest.mark.gpu
+def test_lanes_match_single_stream(gpu, monkeypatch):
+    """The executor runs the two branches of every hourglass level on separate HIP streams (net.h: lanes).
+    Five training micro-steps + an eval forward with lanes on must reproduce a DR_SINGLE_STREAM=1 handle: maps
+    bit-exact in eval (no atomics there), gradients to fp64-atomic rounding noise.  A missing event edge shows up
+    as a gross mismatch in some repetition."""
+    cfg, params, ndm, poses, cfgs, coms = _case(2, 64, 8, 6, 'nyu')
+    B = ndm.shape[0]
+
+    def run(single):
+        if single:
+            monkeypatch.setenv('DR_SINGLE_STREAM', '1')
+        else:
+            monkeypatch.delenv('DR_SINGLE_STREAM', raising=False)
+        h = gpu.handle(cfg, B, training=True)
+        h.load_params(params)
+        h.call('dr_finalize_params', gpu.stream)
+        d_dm, d_pose, d_cfg, d_com, d_lo = gpu.dev(ndm), gpu.dev(poses), gpu.dev(cfgs), gpu.dev(coms), gpu.empty((4,))
+        grads = []
+        for _ in range(5):
+            h.call('dr_forward_train', B, gpu.ptr(d_dm), 0, None, C.c_uint64(0), gpu.stream)
+            h.call('dr_loss', B, gpu.ptr(d_dm), gpu.ptr(d_pose), gpu.ptr(d_cfg), gpu.ptr(d_com), gpu.ptr(d_lo), gpu.stream)
+            h.call('dr_zero_grad', gpu.stream)
+            h.call('dr_backward', B, gpu.stream)
+            gpu.sync()
+            grads.append(flat_grads_by_name(gpu, h, cfg))
+        maps = gpu.forward_eval(h, ndm)
+        h.close()
+        return grads, maps
+
+    g_multi, m_multi = run(False)
+    g_single, m_single = run(True)
+    for a, b in zip(m_multi, m_single):
+        np.testing.assert_array_equal(a, b)
+    for step, (ga, gb) in enumerate(zip(g_multi, g_single)):
+        for name in ga:
+            sc = np.abs(gb[name]).max() + 1e-12
+            assert np.abs(ga[name] - gb[name]).max() / sc < 1e-4, (step, name)
+
+
 WGRAD_CASES = [
     # B, H, W, Cin, Cout, k, T, nsplit, masked
     (2, 8, 8, 64, 64, 3, 64, 3, False),

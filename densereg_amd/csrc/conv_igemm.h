@@ -23,7 +23,9 @@
 //
 // Epilogue (per lane = one output channel, 16 rows):  v = acc*scale[n] + shift[n]; relu;
 // dropout keep mask (x2); + residual;  optional per-channel sum / sum-of-squares of the RAW
-// accumulator for train-mode BatchReNorm (tf.nn.moments, ops.py:132) via fp64 atomics.
+// accumulator for train-mode BatchReNorm (tf.nn.moments, ops.py:132): one fp64 partial row per workgroup,
+// folded in a fixed order by bn_fwd_finalize_kernel (no floating-point atomics: same-address fp64 atomics
+// serialise at ~90 ns each on this part, and a fixed order makes the training step reproducible).
 #pragma once
 #include <type_traits>
 
@@ -45,7 +47,7 @@ struct ConvParams {
     const unsigned char* drop;                       // nullable: keep mask [M][Cout], kept -> x2
     int drop_rng; unsigned long long drop_seed;      // drop_rng != 0: counter-based keep bit instead of `drop`
     const float* out_rowmask; float out_mask_thresh; // nullable: rows with out_rowmask[m] < thresh are not written
-    double* stat_sum; double* stat_sq;               // nullable: per-channel moments of acc
+    double* stat_part;                               // nullable: [gridDim.x][2][Cout] per-workgroup sum / sum-of-squares of acc
     const float* zeros;                              // >= 16 B of zeros in HBM: target of predicated-off loads
 };
 
@@ -356,17 +358,28 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN>())) void conv_igemm_ke
             }
         }
     }
-    if (p.stat_sum) {
+    if (p.stat_part) {
+        // wave partials -> LDS (the operand tiles are dead: the K loop ended on a barrier) -> one row per workgroup
+        double* red = reinterpret_cast<double*>(&As[0][0][0]);              // [2][WM][BN] doubles <= sizeof(As)
+        static_assert(sizeof(As) >= sizeof(double) * 2 * WM * BN, "stat scratch does not fit the A tile");
 #pragma unroll
         for (int j = 0; j < T::kTN; ++j) {
-            const int n = n0 + wn * T::kWTN + j * 32 + li;
             double a = s1[j], b = s2[j];
             a += __shfl_xor(a, 32);
             b += __shfl_xor(b, 32);
-            if (lk == 0 && n < p.Cout) {
-                atomicAdd(&p.stat_sum[n], a);
-                atomicAdd(&p.stat_sq[n], b);
+            if (lk == 0) {
+                const int col = wn * T::kWTN + j * 32 + li;
+                red[(0 * WM + wm) * BN + col] = a;
+                red[(1 * WM + wm) * BN + col] = b;
             }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, col = tid % BN, n = n0 + col;
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + col];
+            if (n < p.Cout) p.stat_part[((long)blockIdx.x * 2 + which) * p.Cout + n] = t;
         }
     }
 }

@@ -65,6 +65,13 @@ int conv_tile_id(const ConvParams& p) {
     return KID_CONV_128x32;
 }
 
+// rows of ConvParams::stat_part the launch writes = workgroups along M of the chosen tile
+int conv_stat_rows(const ConvParams& p) {
+    const int M = p.B * p.H * p.W;
+    const int t = conv_tile_id(p);
+    return dr_ceil_div(M, (t == KID_CONV_64x128 || t == KID_CONV_64x64) ? 64 : 128);
+}
+
 int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     if (p.x_cs % 4 || p.x_coff % 4 || p.Kp % 16 || p.Np % 32 || !p.zeros) return -1;
     // the kernel addresses every tensor with 32-bit element offsets from its base pointer
@@ -372,8 +379,11 @@ static void free_all(dr_handle* h) {
     for (int l = 1; l < DR_MAX_LANES; ++l) {
         if (h->scratch_l[l]) rt::dfree(h->scratch_l[l]);
         if (h->wg_partial_l[l]) rt::dfree(h->wg_partial_l[l]);
+        if (h->bn_coef_l[l]) rt::dfree(h->bn_coef_l[l]);
         rt::stream_destroy(h->lane_stream[l]);
     }
+    for (int l = 0; l < DR_MAX_LANES; ++l)
+        if (h->stat_part_l[l]) rt::dfree(h->stat_part_l[l]);
     for (auto& e : h->lane_ev) rt::event_destroy(e);
 }
 
@@ -878,15 +888,22 @@ extern "C" int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, cons
     p.w = wp; p.Kp = Kp; p.Np = Np; p.y = y; p.y_cs = y_cs; p.y_coff = 0; p.Cout = Cout;
     p.scale = scale; p.shift = shift; p.relu = relu; p.res = res; p.res_cs = res_cs; p.res_coff = 0;
     p.rowmask = rowmask; p.mask_thresh = thresh;
-    p.stat_sum = stat; p.stat_sq = stat ? stat + Cout : nullptr;
+    double* part = nullptr;
+    if (stat) {
+        part = (double*)rt::dmalloc((size_t)dr_ceil_div(B * H * W, 64) * 2 * Cout * sizeof(double));
+        if (!part) return DR_E_NOMEM;
+        p.stat_part = part;
+    }
     float* zeros = (float*)rt::dmalloc(256);
     if (!zeros) return DR_E_NOMEM;
     rt::memset_async(zeros, 0, 256, s);
     p.zeros = zeros;
     int rc = launch_conv_igemm(p, s);
+    if (!rc && stat) DR_LAUNCH(stat_fold_kernel, dim3(dr_ceil_div(Cout, 16)), dim3(256), 0, s, (const double*)part, conv_stat_rows(p), Cout, stat);
     rt::sync_stream(s);
     rt::dfree(wp);
     rt::dfree(zeros);
+    if (part) rt::dfree(part);
     std::string m;
     if (rc || rt::last_error(&m)) return DR_E_DEVICE;
     return DR_OK;
@@ -916,6 +933,72 @@ extern "C" int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const
     DR_LAUNCH(wgrad_reduce_kernel, dim3(grid_for((long)per, 64)), dim3(256), 0, s, (const float*)partial, nsplit, (long)per, dw);
     rt::sync_stream(s);
     rt::dfree(partial);
+    std::string m;
+    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
+}
+
+// Micro-benchmark of the three BatchReNorm streaming kernels on an [M][C] tensor: microseconds per launch of
+// (train apply, backward reduce, backward apply); `reduce_blocks` overrides the backward-reduce grid (0 = executor's).
+extern "C" int dr_dbg_bn_bench(long M, int C, int reduce_blocks, int iters, float* us_out) {
+    if (!us_out || M < 1 || C < 1 || C > 1024 || iters < 1) return DR_E_INVALID;
+    const int cs = dr_round_up(C, 4);
+    const size_t n = (size_t)M * cs;
+    float* raw = (float*)rt::dmalloc(n * 4); float* out = (float*)rt::dmalloc(n * 4); float* dout = (float*)rt::dmalloc(n * 4);
+    float* draw = (float*)rt::dmalloc(n * 4);
+    float* small = (float*)rt::dmalloc(16 * 1024 * 4);        // beta gamma mm mv mm_next mv_next scale shift bnc[4] shadow[2]
+    double* stats = (double*)rt::dmalloc(4 * 1024 * 8);
+    double* bpart = (double*)rt::dmalloc((size_t)2048 * 2 * 1024 * 8);
+    if (!raw || !out || !dout || !draw || !small || !stats || !bpart) return DR_E_NOMEM;
+
+    std::vector<float> hr(n), hs(16 * 1024, 1.0f);
+    unsigned st = 777u;
+    for (auto& v : hr) { st = st * 1664525u + 1013904223u; v = ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
+    rt::h2d(raw, hr.data(), n * 4, nullptr); rt::h2d(dout, hr.data(), n * 4, nullptr);
+    rt::h2d(small, hs.data(), hs.size() * 4, nullptr);
+    std::vector<double> hst(4 * 1024, 0.0);
+    for (int c = 0; c < C; ++c) { hst[c] = 0.1 * M; hst[C + c] = 0.5 * M; }       // one partial row: [2][C]
+    rt::h2d(stats, hst.data(), hst.size() * 8, nullptr);
+    rt::sync_stream(nullptr);
+    BnTrainParams fp{};
+    fp.raw = raw; fp.raw_cs = cs; fp.M = M; fp.C = C; fp.part = stats; fp.part_rows = 1;
+    fp.beta = small; fp.gamma = small + 1024; fp.mm = small + 2048; fp.mv = small + 3072;
+    fp.mm_next = small + 4096; fp.mv_next = small + 5120; fp.shadow_mean = small + 14336; fp.shadow_var = small + 15360; fp.shadow_step = 3;
+    fp.r_max = 3.f; fp.d_max = 5.f; fp.eps = 0.001f; fp.decay = 0.99f;
+    fp.scale = small + 6144; fp.shift = small + 7168; fp.bnc = small + 8192; fp.relu = 1;
+    fp.res = View{nullptr, 0, 0, 0}; fp.out = View{out, cs, 0, C};
+    BnBwdParams bp{};
+    bp.dout = View{dout, cs, 0, C}; bp.raw = raw; bp.raw_cs = cs; bp.M = M; bp.C = C; bp.relu = 1;
+    bp.scale = small + 6144; bp.shift = small + 7168; bp.bnc = small + 8192; bp.gamma = small + 1024;
+    bp.dbeta = small + 12288; bp.dgamma = small + 13312; bp.draw = draw; bp.coef = small + 9216;
+    const int rpb = 256 / (cs / 4);
+    const int g_apply = grid_for(M, rpb, 2048);
+    const int g_reduce = reduce_blocks > 0 ? reduce_blocks : grid_for(M, rpb * 8, 256);
+    bp.part = bpart; bp.part_rows = g_reduce;
+    auto time_it = [&](int which) {
+        auto launch = [&]() {
+            if (which == 0) {
+                DR_LAUNCH(bn_fwd_finalize_kernel, dim3(dr_ceil_div(C, 16)), dim3(256), 0, (hipStream_t) nullptr, fp);
+                DR_LAUNCH(bn_train_apply_kernel, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, fp);
+            } else if (which == 1) {
+                DR_LAUNCH(bn_bwd_reduce_kernel, dim3(g_reduce), dim3(256), 0, (hipStream_t) nullptr, bp);
+                DR_LAUNCH(bn_bwd_finalize_kernel, dim3(dr_ceil_div(C, 16)), dim3(256), 0, (hipStream_t) nullptr, bp);
+            } else {
+                DR_LAUNCH(bn_bwd_apply_kernel, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, bp);
+            }
+        };
+        for (int i = 0; i < 3; ++i) launch();
+        rt::sync_stream(nullptr);
+        rt::Event a = rt::event_create(), b = rt::event_create();
+        rt::event_record(a, nullptr);
+        for (int i = 0; i < iters; ++i) launch();
+        rt::event_record(b, nullptr);
+        rt::sync_stream(nullptr);
+        const float us = rt::event_elapsed_ms(a, b) * 1e3f / iters;
+        rt::event_destroy(a); rt::event_destroy(b);
+        return us;
+    };
+    for (int w = 0; w < 3; ++w) us_out[w] = time_it(w);
+    for (void* q : {(void*)raw, (void*)out, (void*)dout, (void*)draw, (void*)small, (void*)stats, (void*)bpart}) rt::dfree(q);
     std::string m;
     return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
 }

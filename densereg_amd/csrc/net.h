@@ -151,6 +151,9 @@ struct dr_handle {
     dr::RegSeg* reg_segs = nullptr; int n_reg = 0;        // weight segments with weight_decay > 0
     double* loss_acc = nullptr;                            // 4 doubles: hm, hm3, um, reg
     float* bn_coef = nullptr;                              // 3*max(cout) floats (BatchReNorm backward)
+    float* bn_coef_l[dr::DR_MAX_LANES] = {};                // one per lane (index 0 aliases `bn_coef`)
+    double* stat_part_l[dr::DR_MAX_LANES] = {};             // per lane: partial-sum rows of the BatchReNorm reductions
+    size_t n_stat_part = 0;
     float* wg_partial = nullptr; size_t n_wg_partial = 0;  // split-K slabs of the weight gradient
     float* wg_partial_l[dr::DR_MAX_LANES] = {};             // one per lane (index 0 aliases `wg_partial`)
     bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold

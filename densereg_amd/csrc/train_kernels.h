@@ -29,7 +29,7 @@ namespace dr {
 // ------------------------------------------------------------------------------------------------
 struct BnTrainParams {
     const float* raw; int raw_cs; long M; int C;
-    const double* sum; const double* sq;
+    const double* part; int part_rows;          // [part_rows][2][C] partial sum / sum-of-squares rows (conv epilogue)
     const float* beta; const float* gamma;
     const float* mm; const float* mv;           // moving stats BEFORE this step
     float* mm_next; float* mv_next;             // moving stats AFTER this step
@@ -46,9 +46,8 @@ struct BnTrainParams {
 // these passes at ~3 TB/s of the ~8 TB/s HBM.
 constexpr int kBnRows = 4;
 
-__device__ __forceinline__ void bn_channel_coeffs(const BnTrainParams& p, int c, float& sc_out, float& sh_out, bool persist) {
+__device__ __forceinline__ void bn_channel_coeffs(const BnTrainParams& p, int c, double sum, double sq, float& sc_out, float& sh_out, bool persist) {
     // every global read first (independent, one round trip), then the arithmetic, then the stores
-    const double sum = p.sum[c], sq = p.sq[c];
     const float mm = p.mm[c], mv = p.mv[c], g = p.gamma[c], beta = p.beta[c];
     float sh_m = 0.f, sh_v = 0.f;
     if (persist && p.shadow_step > 0) { sh_m = p.shadow_mean[c]; sh_v = p.shadow_var[c]; }
@@ -90,22 +89,70 @@ __device__ __forceinline__ void bn_channel_coeffs(const BnTrainParams& p, int c,
     }
 }
 
-__global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams p) {
-    // scale/shift of every channel once per workgroup (one channel per thread), shared through LDS
-    __shared__ float s_sc[1024], s_sh[1024];
-    for (int c = threadIdx.x; c < p.raw_cs; c += 256) {
-        float sc = 0.f, sh = 0.f;
-        if (c < p.C) bn_channel_coeffs(p, c, sc, sh, blockIdx.x == 0);
-        s_sc[c] = sc; s_sh[c] = sh;
+// Fold the per-workgroup partial rows of the conv epilogue (fixed order: reproducible) and derive everything the
+// step needs per channel: scale/shift for the apply pass, bnc = (mean, inv_std, r, d) for the backward pass, the
+// new moving statistics.  block = 16 channels x 16 row groups, grid = ceil(C / 16).
+__device__ __forceinline__ void fold_partials_16x16(const double* part, int rows, int C, int c, int grp, bool ok,
+                                                     double (*red)[16][17], double& sum, double& sq) {
+    double a = 0.0, b = 0.0;
+    if (ok) {
+        int r = grp;
+        for (; r + 7 * 16 < rows; r += 8 * 16) {                // 8 independent loads per array in flight
+            double va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                va[u] = part[((long)(r + u * 16) * 2 + 0) * C + c];
+                vb[u] = part[((long)(r + u * 16) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
+        }
+        for (; r < rows; r += 16) { a += part[((long)r * 2 + 0) * C + c]; b += part[((long)r * 2 + 1) * C + c]; }
     }
+    const int cl = threadIdx.x & 15;
+    red[0][cl][grp] = a; red[1][cl][grp] = b;
     __syncthreads();
+    sum = 0.0; sq = 0.0;
+    if (grp == 0) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { sum += red[0][cl][g]; sq += red[1][cl][g]; }
+    }
+}
+
+// plain fold of partial rows into out[0..C) = sum, out[C..2C) = sum of squares (test hook dr_dbg_conv2d)
+__global__ __launch_bounds__(256) void stat_fold_kernel(const double* part, int rows, int C, double* out) {
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double sum, sq;
+    fold_partials_16x16(part, rows, C, c, grp, c < C, red, sum, sq);
+    if (grp == 0 && c < C) { out[c] = sum; out[C + c] = sq; }
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const BnTrainParams p) {
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double sum, sq;
+    fold_partials_16x16(p.part, p.part_rows, p.C, c, grp, c < p.C, red, sum, sq);
+    if (grp == 0 && c < p.C) {
+        float sc, sh;
+        bn_channel_coeffs(p, c, sum, sq, sc, sh, true);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams p) {
     const int c4n = p.raw_cs / 4;                  // channel groups per row (<= 256)
     const int rpb = 256 / c4n;                     // rows per workgroup pass
     const int cg = threadIdx.x % c4n, rp = threadIdx.x / c4n;
     if (rp >= rpb) return;
     float sc[4], sh[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { sc[k] = s_sc[cg * 4 + k]; sh[k] = s_sh[cg * 4 + k]; }
+    for (int k = 0; k < 4; ++k) {
+        const int c = cg * 4 + k;
+        sc[k] = c < p.C ? p.scale[c] : 0.f;                    // written by bn_fwd_finalize_kernel
+        sh[k] = c < p.C ? p.shift[c] : 0.f;
+    }
     const bool full = cg * 4 + 4 <= p.C;
     const bool vec_out = full && (p.out.coff % 4 == 0) && (p.out.cs % 4 == 0);
     const bool vec_res = p.res.p && full && (p.res.coff % 4 == 0) && (p.res.cs % 4 == 0);
@@ -158,14 +205,15 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
 //   out = gamma*(r*yhat + d) + beta, yhat = (x-mean)*inv_std, g = dOut * [out_pre_relu > 0]
 //   dbeta = sum g ; dgamma = r*sum(g*yhat) + d*sum(g)
 //   dx = gamma*r*inv_std * (g - mean(g) - yhat*mean(g*yhat))
-// reduce: per-channel sum g, sum g*yhat (fp64 partials, one atomic per workgroup and channel);
-// apply: every workgroup rebuilds the three dx coefficients from the sums, workgroup 0 also
-// accumulates dbeta/dgamma into the flat gradient.
+// reduce: per-channel sum g, sum g*yhat -- one fp64 partial row per workgroup (no floating-point atomics);
+// finalize: folds the rows in a fixed order, writes the three dx coefficients, accumulates dbeta/dgamma;
+// apply: dx from the coefficients.
 // ------------------------------------------------------------------------------------------------
 struct BnBwdParams {
     View dout; const float* raw; int raw_cs; long M; int C; int relu;
     const float* scale; const float* shift; const float* bnc; const float* gamma;
-    double* sum_g; double* sum_gy;
+    double* part; int part_rows;      // [part_rows][2][C]: per-workgroup sum g / sum g*yhat rows of the reduce pass
+    float* coef;                      // [3][C]: c1 = gamma*r*inv_std, c2 = mean(g), c3 = mean(g*yhat) (finalize -> apply)
     float* dbeta; float* dgamma;      // flat-gradient slices (accumulated)
     float* draw;                      // out: gradient wrt the raw conv output, dense stride raw_cs
 };
@@ -238,10 +286,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
             if (c < p.C) {
                 double ta = 0.0, tb = 0.0;
                 for (int r = 0; r < rpb; ++r) { ta += s1[(r * c4n + tid) * 4 + k]; tb += s2[(r * c4n + tid) * 4 + k]; }
-                atomicAdd(&p.sum_g[c], ta);
-                atomicAdd(&p.sum_gy[c], tb);
+                p.part[((long)blockIdx.x * 2 + 0) * p.C + c] = ta;
+                p.part[((long)blockIdx.x * 2 + 1) * p.C + c] = tb;
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdParams p) {
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double sg, sgy;
+    fold_partials_16x16(p.part, p.part_rows, p.C, c, grp, c < p.C, red, sg, sgy);
+    if (grp == 0 && c < p.C) {
+        const float r = p.bnc[2 * p.C + c], d = p.bnc[3 * p.C + c], istd = p.bnc[p.C + c];
+        p.coef[0 * p.C + c] = p.gamma[c] * r * istd;
+        p.coef[1 * p.C + c] = (float)(sg / (double)p.M);
+        p.coef[2 * p.C + c] = (float)(sgy / (double)p.M);
+        p.dbeta[c] += (float)sg;
+        p.dgamma[c] += r * (float)sgy + d * (float)sg;
     }
 }
 
@@ -257,15 +321,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
         sc[k] = sh[k] = mean[k] = istd[k] = c1[k] = c2[k] = c3[k] = 0.f;
         if (c < p.C) {
             sc[k] = p.scale[c]; sh[k] = p.shift[c]; mean[k] = p.bnc[c]; istd[k] = p.bnc[p.C + c];
-            const float r = p.bnc[2 * p.C + c], d = p.bnc[3 * p.C + c];
-            c1[k] = p.gamma[c] * r * istd[k];
-            c2[k] = (float)(p.sum_g[c] / (double)p.M);
-            c3[k] = (float)(p.sum_gy[c] / (double)p.M);
-            if (blockIdx.x == 0 && rp == 0) {
-                const float sg = (float)p.sum_g[c], sgy = (float)p.sum_gy[c];
-                p.dbeta[c] += sg;
-                p.dgamma[c] += r * sgy + d * sg;
-            }
+            c1[k] = p.coef[c]; c2[k] = p.coef[p.C + c]; c3[k] = p.coef[2 * p.C + c];
         }
     }
     const bool full = cg * 4 + 4 <= p.C;

@@ -22,6 +22,10 @@ int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, const float* x,
 int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const float* x, int x_cs, const float* g, int g_cs,
                  const float* rowmask, float thresh, int T, int nsplit, float* dw, dr_stream stream);
 
+/* Micro-benchmark of the BatchReNorm streaming kernels on an [M][C] tensor: us_out[3] = microseconds per launch
+ * of (train apply, backward reduce, backward apply).  reduce_blocks > 0 overrides the backward-reduce grid. */
+int dr_dbg_bn_bench(long M, int C, int reduce_blocks, int iters, float* us_out);
+
 /* Micro-benchmark one conv shape on self-allocated buffers: average milliseconds per launch.
  * tile = -1 (heuristic) or a tile id (0 128x128, 1 64x128, 2 128x64, 3 64x64, 4 128x32);
  * abl = 0 product kernel, 1/2/3 = ablations of the 128x128 kernel (no refills / no MFMA / no stores),

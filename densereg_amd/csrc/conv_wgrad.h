@@ -203,34 +203,40 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
     }
 }
 
-// Stem (7x7/s2, Cin = 1): dW[ky][kx][n] += sum_pix x[b, oy*s+ky-pt, ox*s+kx-pl] * g[pix][n], Cout = 32.
-// block = 256 threads = 8 tap groups x 32 channels over a chunk of 256 output pixels.
+// Stem (7x7/s2, Cin = 1): dW[ky][kx][n] = sum_pix x[b, oy*s+ky-pt, ox*s+kx-pl] * g[pix][n], Cout = 32.
+// block = 256 threads = 8 tap groups x 32 channels over a chunk of `chunk` output pixels; it writes one partial
+// row [k*k][32] (tap-major) that wgrad_reduce_kernel folds into the flat gradient -- no floating-point atomics.
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* x, int B, int H, int W, const float* g, int g_cs, int k,
-                                                         int stride, int pad_t, int pad_l, int Ho, int Wo, float* dw) {
+                                                         int stride, int pad_t, int pad_l, int Ho, int Wo, int chunk, float* partial) {
     const int n = threadIdx.x & 31, tg = threadIdx.x >> 5;
-    const long M = (long)B * Ho * Wo;
-    const long m0 = (long)blockIdx.x * 256;
+    const int M = B * Ho * Wo, HWo = Ho * Wo;
+    const int m0 = blockIdx.x * chunk;
+    const int m1 = m0 + chunk < M ? m0 + chunk : M;
     float acc[7];
+    int ty[7], tx[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) acc[i] = 0.f;
-    for (long m = m0; m < m0 + 256 && m < M; ++m) {
-        const int b = (int)(m / ((long)Ho * Wo));
-        const int rem = (int)(m % ((long)Ho * Wo));
-        const int oy = rem / Wo, ox = rem % Wo;
-        const float gv = g[m * g_cs + n];
+    for (int i = 0; i < 7; ++i) {
+        acc[i] = 0.f;
+        const int tap = tg + 8 * i;
+        ty[i] = tap / k - pad_t; tx[i] = tap % k - pad_l;
+    }
+    int b = m0 / HWo, rem = m0 % HWo;
+    int oy = rem / Wo, ox = rem % Wo;
+    for (int m = m0; m < m1; ++m) {
+        const float gv = g[(long)m * g_cs + n];
+        const float* xb = x + (long)b * H * W;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            const int tap = tg + 8 * i;
-            if (tap < k * k) {
-                const int iy = oy * stride + tap / k - pad_t, ix = ox * stride + tap % k - pad_l;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) acc[i] = fmaf(x[((long)b * H + iy) * W + ix], gv, acc[i]);
-            }
+            const int iy = oy * stride + ty[i], ix = ox * stride + tx[i];
+            if (tg + 8 * i < k * k && iy >= 0 && iy < H && ix >= 0 && ix < W) acc[i] = fmaf(xb[iy * W + ix], gv, acc[i]);
         }
+        if (++ox == Wo) { ox = 0; if (++oy == Ho) { oy = 0; ++b; } }
     }
+    float* row = partial + (long)blockIdx.x * k * k * 32;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         const int tap = tg + 8 * i;
-        if (tap < k * k) atomicAdd(&dw[tap * 32 + n], acc[i]);
+        if (tap < k * k) row[tap * 32 + n] = acc[i];
     }
 }
 

@@ -57,11 +57,19 @@ static int g_force_tile = -1;        // test/bench hook (dr_dbg_conv_bench); -1 
 int conv_tile_id(const ConvParams& p) {
     const int M = p.B * p.H * p.W;
     if (g_force_tile >= 0) return g_force_tile;
-    // Measured on MI355X (profiles/r01_conv_microbench.md): with M = B*H*W = 40960 rows on 256 CUs the
-    // 64-row tiles give balanced grids (1280/2560 workgroups) and beat or tie the 128-row ones on every
-    // shape of this network (3x3 256->256: 92.9 vs 83.6 TFLOP/s); 128-row tiles only pay on much deeper grids.
-    if (p.Np % 128 == 0) return ((long)dr_ceil_div(M, 128) * (p.Np / 128) >= 4096) ? KID_CONV_128x128 : KID_CONV_64x128;
-    if (p.Np % 64 == 0) return ((long)dr_ceil_div(M, 128) * (p.Np / 64) >= 4096) ? KID_CONV_128x64 : KID_CONV_64x64;
+    // Measured on MI355X (profiles/r01_conv_microbench.md): what decides between the tiles of one N width is how
+    // evenly the workgroups fall on the 256 CUs.  M = 40960 rows: Np = 256 / 512 give 1280 / 2560 64x128 workgroups
+    // = 5 / 10 per CU (3x3 256->256: 99 TFLOP/s, 128-row tiles 95); Np = 128 gives 640 = 2.5 per CU, and the 64x64
+    // tile (1280 workgroups) wins by 5-12 % despite re-reading A twice (3x3 128->128: 141 vs 150 us).
+    auto balance = [](long blocks) { return (double)blocks / (double)(dr_ceil_div((int)blocks, 256) * 256); };
+    const long rows64 = dr_ceil_div(M, 64), rows128 = dr_ceil_div(M, 128);
+    if (p.Np % 128 == 0) {
+        const long b128 = rows128 * (p.Np / 128), b64x128 = rows64 * (p.Np / 128), b64x64 = rows64 * (p.Np / 64);
+        if (b128 >= 4096) return KID_CONV_128x128;
+        if (b64x128 < 256 || 0.92 * balance(b64x64) > balance(b64x128)) return KID_CONV_64x64;
+        return KID_CONV_64x128;
+    }
+    if (p.Np % 64 == 0) return (rows128 * (p.Np / 64) >= 4096) ? KID_CONV_128x64 : KID_CONV_64x64;
     return KID_CONV_128x32;
 }
 

@@ -36,7 +36,7 @@ def main():
         np_ = -(-cout // 32) * 32
         variants = [(-1, 0), (-1, 5)]
         if np_ % 128 == 0:
-            variants += [(0, 0), (1, 0), (0, 1), (0, 2), (1, 6), (1, 7), (1, 8), (1, 9)]
+            variants += [(0, 0), (1, 0), (2, 0), (3, 0), (0, 1), (0, 2), (1, 6), (1, 7)]
         elif np_ % 64 == 0:
             variants += [(2, 0), (3, 0)]
         for tile, abl in variants:

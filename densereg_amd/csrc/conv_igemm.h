@@ -47,7 +47,7 @@ struct ConvParams {
     const unsigned char* drop;                       // nullable: keep mask [M][Cout], kept -> x2
     int drop_rng; unsigned long long drop_seed;      // drop_rng != 0: counter-based keep bit instead of `drop`
     const float* out_rowmask; float out_mask_thresh; // nullable: rows with out_rowmask[m] < thresh are not written
-    double* stat_part;                               // nullable: [gridDim.x][2][Cout] per-workgroup sum / sum-of-squares of acc
+    double* stat_part;                               // nullable: [2][Cout][gridDim.x] per-workgroup sum / sum-of-squares of acc
     const float* zeros;                              // >= 16 B of zeros in HBM: target of predicated-off loads
 };
 
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN>())) void conv_igemm_ke
             double t = 0.0;
 #pragma unroll
             for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + col];
-            if (n < p.Cout) p.stat_part[((long)blockIdx.x * 2 + which) * p.Cout + n] = t;
+            if (n < p.Cout) p.stat_part[((long)which * p.Cout + n) * gridDim.x + blockIdx.x] = t;
         }
     }
 }

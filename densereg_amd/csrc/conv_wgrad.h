@@ -187,15 +187,25 @@ __global__ __launch_bounds__(256, (T == 128 ? 3 : 6)) void conv_wgrad_kernel(con
     }
 }
 
-// dst[i] += sum_s partial[s][i].  block = 64 elements x 4 split lanes, folded through LDS.
+// dst[i] += sum_s partial[s][i].  block = 64 elements x 4 split lanes, folded through LDS in a fixed order.
+// The slab loads of a lane are issued in batches of 8 independent loads (a plain accumulate loop waits for each).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, int nsplit, long n, float* dst) {
     __shared__ float red[4][64];
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
     for (long base = (long)blockIdx.x * 64; base < n; base += (long)gridDim.x * 64) {
         const long i = base + e;
         float s = 0.f;
-        if (i < n)
-            for (int k = sl; k < nsplit; k += 4) s += partial[(long)k * n + i];
+        if (i < n) {
+            int k = sl;
+            for (; k + 7 * 4 < nsplit; k += 8 * 4) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = partial[(long)(k + u * 4) * n + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; k < nsplit; k += 4) s += partial[(long)k * n + i];
+        }
         red[sl][e] = s;
         __syncthreads();
         if (sl == 0 && i < n) dst[i] += (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);

@@ -907,7 +907,7 @@ extern "C" int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, cons
     rt::memset_async(zeros, 0, 256, s);
     p.zeros = zeros;
     int rc = launch_conv_igemm(p, s);
-    if (!rc && stat) DR_LAUNCH(stat_fold_kernel, dim3(dr_ceil_div(Cout, 16)), dim3(256), 0, s, (const double*)part, conv_stat_rows(p), Cout, stat);
+    if (!rc && stat) DR_LAUNCH(stat_fold_kernel, dim3(dr_ceil_div(Cout, 4)), dim3(256), 0, s, (const double*)part, conv_stat_rows(p), Cout, stat);
     rt::sync_stream(s);
     rt::dfree(wp);
     rt::dfree(zeros);
@@ -985,11 +985,11 @@ extern "C" int dr_dbg_bn_bench(long M, int C, int reduce_blocks, int iters, floa
     auto time_it = [&](int which) {
         auto launch = [&]() {
             if (which == 0) {
-                DR_LAUNCH(bn_fwd_finalize_kernel, dim3(dr_ceil_div(C, 16)), dim3(256), 0, (hipStream_t) nullptr, fp);
+                DR_LAUNCH(bn_fwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, (hipStream_t) nullptr, fp);
                 DR_LAUNCH(bn_train_apply_kernel, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, fp);
             } else if (which == 1) {
                 DR_LAUNCH(bn_bwd_reduce_kernel, dim3(g_reduce), dim3(256), 0, (hipStream_t) nullptr, bp);
-                DR_LAUNCH(bn_bwd_finalize_kernel, dim3(dr_ceil_div(C, 16)), dim3(256), 0, (hipStream_t) nullptr, bp);
+                DR_LAUNCH(bn_bwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, (hipStream_t) nullptr, bp);
             } else {
                 DR_LAUNCH(bn_bwd_apply_kernel, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, bp);
             }

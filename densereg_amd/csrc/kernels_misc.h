@@ -138,6 +138,23 @@ __global__ __launch_bounds__(256) void uvd_kernel(const float* dm, int B, int in
 // dst(m, c) (+)= src(m, c) for c < C
 __global__ __launch_bounds__(256) void copy_channels_kernel(const float* src, int s_cs, int s_coff, float* dst, int d_cs,
                                                             int d_coff, long M, int C, int accumulate) {
+    if (((C | s_cs | s_coff | d_cs | d_coff) & 3) == 0) {                 // uniform: 16-byte rows on both sides
+        const int c4n = C / 4;
+        const long total = M * c4n;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const int c = int(i % c4n) * 4;
+            const long m = i / c4n;
+            const float4 v = *reinterpret_cast<const float4*>(src + m * s_cs + s_coff + c);
+            float4* q = reinterpret_cast<float4*>(dst + m * d_cs + d_coff + c);
+            if (accumulate) {
+                const float4 o = *q;
+                *q = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+            } else {
+                *q = v;
+            }
+        }
+        return;
+    }
     const long total = M * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = int(i % C);

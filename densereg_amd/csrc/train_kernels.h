@@ -29,7 +29,7 @@ namespace dr {
 // ------------------------------------------------------------------------------------------------
 struct BnTrainParams {
     const float* raw; int raw_cs; long M; int C;
-    const double* part; int part_rows;          // [part_rows][2][C] partial sum / sum-of-squares rows (conv epilogue)
+    const double* part; int part_rows;          // [2][C][part_rows] partial sums / sums of squares (conv epilogue)
     const float* beta; const float* gamma;
     const float* mm; const float* mv;           // moving stats BEFORE this step
     float* mm_next; float* mv_next;             // moving stats AFTER this step
@@ -89,53 +89,46 @@ __device__ __forceinline__ void bn_channel_coeffs(const BnTrainParams& p, int c,
     }
 }
 
-// Fold the per-workgroup partial rows of the conv epilogue (fixed order: reproducible) and derive everything the
-// step needs per channel: scale/shift for the apply pass, bnc = (mean, inv_std, r, d) for the backward pass, the
-// new moving statistics.  block = 16 channels x 16 row groups, grid = ceil(C / 16).
-__device__ __forceinline__ void fold_partials_16x16(const double* part, int rows, int C, int c, int grp, bool ok,
-                                                     double (*red)[16][17], double& sum, double& sq) {
+// Fold the per-workgroup partials of the conv epilogue / the backward reduce and derive everything the step
+// needs per channel.  Partials are stored [2][C][rows] -- the rows of one channel are contiguous -- so one wave folds
+// one channel with coalesced loads and a fixed shuffle tree (reproducible); block = 4 waves = 4 channels.
+__device__ __forceinline__ void fold_partials_wave(const double* part, int rows, int C, int c, double& sum, double& sq) {
+    const int lane = threadIdx.x & 63;
+    const double* pa = part + (long)c * rows;
+    const double* pb = part + ((long)C + c) * rows;
     double a = 0.0, b = 0.0;
-    if (ok) {
-        int r = grp;
-        for (; r + 7 * 16 < rows; r += 8 * 16) {                // 8 independent loads per array in flight
-            double va[8], vb[8];
+    int r = lane;
+    for (; r + 3 * 64 < rows; r += 4 * 64) {
+        double va[4], vb[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                va[u] = part[((long)(r + u * 16) * 2 + 0) * C + c];
-                vb[u] = part[((long)(r + u * 16) * 2 + 1) * C + c];
-            }
+        for (int u = 0; u < 4; ++u) { va[u] = pa[r + u * 64]; vb[u] = pb[r + u * 64]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
-        }
-        for (; r < rows; r += 16) { a += part[((long)r * 2 + 0) * C + c]; b += part[((long)r * 2 + 1) * C + c]; }
+        for (int u = 0; u < 4; ++u) { a += va[u]; b += vb[u]; }
     }
-    const int cl = threadIdx.x & 15;
-    red[0][cl][grp] = a; red[1][cl][grp] = b;
-    __syncthreads();
-    sum = 0.0; sq = 0.0;
-    if (grp == 0) {
+    for (; r < rows; r += 64) { a += pa[r]; b += pb[r]; }
 #pragma unroll
-        for (int g = 0; g < 16; ++g) { sum += red[0][cl][g]; sq += red[1][cl][g]; }
+    for (int o = 32; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
     }
+    sum = a; sq = b;
 }
 
-// plain fold of partial rows into out[0..C) = sum, out[C..2C) = sum of squares (test hook dr_dbg_conv2d)
+// plain fold into out[0..C) = sum, out[C..2C) = sum of squares (test hook dr_dbg_conv2d)
 __global__ __launch_bounds__(256) void stat_fold_kernel(const double* part, int rows, int C, double* out) {
-    __shared__ double red[2][16][17];
-    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
     double sum, sq;
-    fold_partials_16x16(part, rows, C, c, grp, c < C, red, sum, sq);
-    if (grp == 0 && c < C) { out[c] = sum; out[C + c] = sq; }
+    fold_partials_wave(part, rows, C, c, sum, sq);
+    if ((threadIdx.x & 63) == 0) { out[c] = sum; out[C + c] = sq; }
 }
 
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const BnTrainParams p) {
-    __shared__ double red[2][16][17];
-    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= p.C) return;
     double sum, sq;
-    fold_partials_16x16(p.part, p.part_rows, p.C, c, grp, c < p.C, red, sum, sq);
-    if (grp == 0 && c < p.C) {
+    fold_partials_wave(p.part, p.part_rows, p.C, c, sum, sq);
+    if ((threadIdx.x & 63) == 0) {
         float sc, sh;
         bn_channel_coeffs(p, c, sum, sq, sc, sh, true);
     }
@@ -212,7 +205,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
 struct BnBwdParams {
     View dout; const float* raw; int raw_cs; long M; int C; int relu;
     const float* scale; const float* shift; const float* bnc; const float* gamma;
-    double* part; int part_rows;      // [part_rows][2][C]: per-workgroup sum g / sum g*yhat rows of the reduce pass
+    double* part; int part_rows;      // [2][C][part_rows]: per-workgroup sum g / sum g*yhat of the reduce pass
     float* coef;                      // [3][C]: c1 = gamma*r*inv_std, c2 = mean(g), c3 = mean(g*yhat) (finalize -> apply)
     float* dbeta; float* dgamma;      // flat-gradient slices (accumulated)
     float* draw;                      // out: gradient wrt the raw conv output, dense stride raw_cs
@@ -286,20 +279,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
             if (c < p.C) {
                 double ta = 0.0, tb = 0.0;
                 for (int r = 0; r < rpb; ++r) { ta += s1[(r * c4n + tid) * 4 + k]; tb += s2[(r * c4n + tid) * 4 + k]; }
-                p.part[((long)blockIdx.x * 2 + 0) * p.C + c] = ta;
-                p.part[((long)blockIdx.x * 2 + 1) * p.C + c] = tb;
+                p.part[(long)c * gridDim.x + blockIdx.x] = ta;                    // [2][C][rows]
+                p.part[((long)p.C + c) * gridDim.x + blockIdx.x] = tb;
             }
         }
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdParams p) {
-    __shared__ double red[2][16][17];
-    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= p.C) return;
     double sg, sgy;
-    fold_partials_16x16(p.part, p.part_rows, p.C, c, grp, c < p.C, red, sg, sgy);
-    if (grp == 0 && c < p.C) {
+    fold_partials_wave(p.part, p.part_rows, p.C, c, sg, sgy);
+    if ((threadIdx.x & 63) == 0) {
         const float r = p.bnc[2 * p.C + c], d = p.bnc[3 * p.C + c], istd = p.bnc[p.C + c];
         p.coef[0 * p.C + c] = p.gamma[c] * r * istd;
         p.coef[1 * p.C + c] = (float)(sg / (double)p.M);
@@ -390,24 +382,36 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(View dout, View out, int r
     }
 }
 
-// dst[c] += sum_m g(m,c)    (bias gradient)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* g, int cs, int coff, long M, int C, float* dst) {
+// part[blockIdx.x][c] = sum over this workgroup's rows of g(m,c)  (bias gradient; wgrad_reduce_kernel folds the
+// rows into the flat gradient in a fixed order -- no floating-point atomics)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* g, int cs, int coff, long M, int C, float* part) {
     __shared__ double s1[256];
     const int tid = threadIdx.x;
     const int cpb = C < 256 ? C : 256;
     const int rows_par = 256 / cpb;
+    const long stride = (long)gridDim.x * rows_par;
     for (int c0 = 0; c0 < C; c0 += cpb) {
         const int c = c0 + tid % cpb;
         const int rp = tid / cpb;
         double a = 0.0;
-        if (rp < rows_par && c < C)
-            for (long m = (long)blockIdx.x * rows_par + rp; m < M; m += (long)gridDim.x * rows_par) a += (double)g[m * cs + coff + c];
+        if (rp < rows_par && c < C) {
+            long m = (long)blockIdx.x * rows_par + rp;
+            const float* col = g + coff + c;
+            for (; m + 7 * stride < M; m += 8 * stride) {          // 8 independent loads in flight
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = col[(m + u * stride) * cs];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += (double)v[u];
+            }
+            for (; m < M; m += stride) a += (double)col[m * cs];
+        }
         s1[tid] = a;
         __syncthreads();
         if (tid < cpb && c0 + tid < C) {
             double ta = 0.0;
             for (int r = 0; r < rows_par; ++r) ta += s1[r * cpb + tid];
-            atomicAdd(&dst[c0 + tid], (float)ta);
+            part[(long)blockIdx.x * C + c0 + tid] = (float)ta;
         }
         __syncthreads();
     }

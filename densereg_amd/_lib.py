@@ -60,6 +60,9 @@ SIGNATURES = {
     'dr_apply_adam': (_i, [_vp, C.c_float, C.c_float, C.c_float, C.c_int64, _vp]),
     'dr_read_activation': (_i, [_vp, C.c_char_p, _i, _fp, _sz]),
     'dr_conv_flops_per_crop': (C.c_double, [_vp]),
+    'dr_crop_from_pose': (_i, [_i, _vp, _i, _i, _vp, _i, _vp, _i, C.c_float, _i, _vp, _vp, _vp, _vp]),
+    'dr_crop_from_bbx': (_i, [_i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    'dr_data_aug': (_i, [_i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     # include/densereg_debug.h (test hooks)
     'dr_dbg_conv_bench': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
     'dr_dbg_force_tile': (_i, [_i]),

@@ -7,6 +7,7 @@
 
 #include "conv_igemm.h"
 #include "conv_wgrad.h"
+#include "frontend.h"
 #include "kernels_misc.h"
 #include "net.h"
 #include "train_kernels.h"
@@ -670,6 +671,43 @@ int dr_finalize_params(dr_handle* h, dr_stream stream) {
     h->finalized = true;
     h->fold_is_eval = true;
     return DR_OK;
+}
+
+// ---- input front-end: handle-free, one workgroup per frame (frontend.h) --------------------------------------
+int dr_crop_from_pose(int B, const float* frames, int H, int W, const float* pose, int J, const float* cfg, int icvl, float pad,
+                      int out_hw, float* crops, float* new_cfg, float* com, dr_stream stream) {
+    if (!frames || !pose || !cfg || !crops || !new_cfg || !com) return DR_E_INVALID;
+    if (B < 1 || H < 1 || W < 1 || J < 1 || out_hw < 2 || !(pad > 0.f) || (long)H * W >= (1l << 31)) return DR_E_INVALID;
+    CropParams p{};
+    p.frames = frames; p.H = H; p.W = W; p.pose = pose; p.J = J; p.bbx = nullptr; p.cfg = cfg; p.icvl = icvl; p.pad = pad;
+    p.out_hw = out_hw; p.crops = crops; p.new_cfg = new_cfg; p.com = com;
+    DR_LAUNCH(crop_com_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p);
+    std::string m;
+    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
+}
+
+int dr_crop_from_bbx(int B, const float* frames, int H, int W, const float* bbx, const float* cfg, int out_hw, float* crops,
+                     float* new_cfg, float* com, dr_stream stream) {
+    if (!frames || !bbx || !cfg || !crops || !new_cfg || !com) return DR_E_INVALID;
+    if (B < 1 || H < 1 || W < 1 || out_hw < 2 || (long)H * W >= (1l << 31)) return DR_E_INVALID;
+    CropParams p{};
+    p.frames = frames; p.H = H; p.W = W; p.pose = nullptr; p.J = 0; p.bbx = bbx; p.cfg = cfg; p.icvl = 0; p.pad = 20.f;
+    p.out_hw = out_hw; p.crops = crops; p.new_cfg = new_cfg; p.com = com;
+    DR_LAUNCH(crop_com_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p);
+    std::string m;
+    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
+}
+
+int dr_data_aug(int B, const float* dms, int H, int W, const float* pose, int J, const float* cfg, const float* com,
+                const float* draws, float* out_dms, float* out_pose, dr_stream stream) {
+    if (!dms || !pose || !cfg || !com || !draws || !out_dms || !out_pose) return DR_E_INVALID;
+    if (B < 1 || H < 1 || W < 1 || J < 1 || J > 256 || dms == out_dms) return DR_E_INVALID;
+    AugParams p{};
+    p.dms = dms; p.H = H; p.W = W; p.pose = pose; p.J = J; p.cfg = cfg; p.com = com; p.draws = draws;
+    p.out_dms = out_dms; p.out_pose = out_pose;
+    DR_LAUNCH(data_aug_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p);
+    std::string m;
+    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
 }
 
 int dr_norm_dm(dr_handle* h, int B, const float* dm, const float* com, float* out, dr_stream stream) {

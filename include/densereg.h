@@ -73,6 +73,29 @@ int dr_read_param(dr_handle* h, const char* name, float* host, size_t count);
  * forward.  Synchronises. */
 int dr_finalize_params(dr_handle* h, dr_stream stream);
 
+/* ---- input front-end: raw frame -> crop + centre of mass, augmentation ------------- */
+/* All pointers are device pointers; these three entry points need no handle (no weights, no workspace) and run
+ * on the current device.  One launch per call, nothing synchronises.
+ *
+ * data/preprocess.py:10-79 crop_from_xyz_pose + :131-142 center_of_mass.  frames (B,H,W) depth in mm, pose (B,3J)
+ * xyz in mm (ground truth at training time, the previous estimate when tracking), cfg (B,6) = fx,fy,cx,cy,w,h of
+ * the frame.  Box = projected joints +- pad pixels, cropped, zero padded to a square, bilinear-resized
+ * (tf.image.resize_images defaults) to out_hw x out_hw, background removed (icvl != 0: depth >= 500 -> 0, else
+ * depth >= min joint-pixel depth + 250 -> 0).  Outputs: crops (B,out_hw,out_hw), new_cfg (B,6) the camera of the
+ * crop, com (B,3) = mean positive depth at the centre pixel of the crop, back-projected. */
+int dr_crop_from_pose(int B, const float* frames_dev, int H, int W, const float* pose_mm_dev, int J, const float* cfg_dev,
+                      int icvl, float pad, int out_hw, float* crops_dev, float* new_cfg_dev, float* com_dev,
+                      dr_stream stream);
+/* data/preprocess.py:81-129 crop_from_bbx + center_of_mass: bbx (B,5) = top,left,bottom,right,depth threshold. */
+int dr_crop_from_bbx(int B, const float* frames_dev, int H, int W, const float* bbx_dev, const float* cfg_dev, int out_hw,
+                     float* crops_dev, float* new_cfg_dev, float* com_dev, dr_stream stream);
+/* data/preprocess.py:234-268 data_aug: rotate about the image centre (nearest), rescale rows/columns by
+ * ratio_h/ratio_w (nearest), centre crop-or-pad back to (H,W); the pose follows in uvd space around the centre of
+ * mass.  draws (B,3) = angle [rad], ratio_h, ratio_w -- the reference draws U(-pi,pi) and clip(N(1,.2),.9,1.1);
+ * the caller supplies them (the Python host draws them, parity tests inject them). */
+int dr_data_aug(int B, const float* dms_dev, int H, int W, const float* pose_mm_dev, int J, const float* cfg_dev,
+                const float* com_dev, const float* draws_dev, float* out_dms_dev, float* out_pose_dev, dr_stream stream);
+
 /* ---- pre-processing on the path --------------------------------------------------------------- */
 /* data/preprocess.py:176-187 norm_dm: dm_mm (B,hw,hw,1), com (B,3) -> dm_norm (B,hw,hw,1) */
 int dr_norm_dm(dr_handle* h, int B, const float* dm_mm_dev, const float* com_dev, float* dm_norm_dev,

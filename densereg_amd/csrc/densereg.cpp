@@ -582,6 +582,23 @@ static const ParamInfo* find_param(const dr_handle* h, const char* name) {
     return nullptr;
 }
 
+// Zero-debias slot variables of assign_moving_average ([TF1.3-semantics] moving_averages.py): "<var>/biased" (the
+// un-corrected accumulator, same shape as the moving statistic) and "<var>/local_step" (one float, the number of
+// updates).  They are not listed by dr_param_info (TF creates them lazily and a Saver checkpoint names them with
+// the scope repeated); dr_load_param / dr_read_param accept them by these names so a checkpoint importer can
+// carry the exact BatchReNorm state over.  Returns the base variable, *slot = 1 biased, 2 local_step.
+static const ParamInfo* find_slot(const dr_handle* h, const char* name, int* slot) {
+    const std::string n(name);
+    for (int k = 1; k <= 2; ++k) {
+        const std::string suf = k == 1 ? "/biased" : "/local_step";
+        if (n.size() > suf.size() && n.compare(n.size() - suf.size(), suf.size(), suf) == 0) {
+            const ParamInfo* p = find_param(h, n.substr(0, n.size() - suf.size()).c_str());
+            if (p && (p->kind == PK_MMEAN || p->kind == PK_MVAR)) { *slot = k; return p; }
+        }
+    }
+    return nullptr;
+}
+
 static float* param_dev_ptr(dr_handle* h, const ParamInfo& p) {
     ConvLayer& c = h->convs[p.conv];
     switch (p.kind) {
@@ -598,7 +615,23 @@ static float* param_dev_ptr(dr_handle* h, const ParamInfo& p) {
 int dr_load_param(dr_handle* h, const char* name, const float* host, size_t count) {
     if (!h || !name || !host) return DR_E_INVALID;
     const ParamInfo* p = find_param(h, name);
-    if (!p) DR_FAIL(h, DR_E_INVALID, "dr_load_param: unknown variable '%s'", name);
+    if (!p) {
+        int slot = 0;
+        const ParamInfo* base = find_slot(h, name, &slot);
+        if (!base) DR_FAIL(h, DR_E_INVALID, "dr_load_param: unknown variable '%s'", name);
+        if (!h->cfg.training) DR_FAIL(h, DR_E_STATE, "dr_load_param: '%s' exists only on a training handle", name);
+        ConvLayer& cl = h->convs[base->conv];
+        if (slot == 2) {
+            if (count != 1) DR_FAIL(h, DR_E_INVALID, "dr_load_param: '%s' is a scalar", name);
+            cl.shadow_step = (int)host[0];
+            return DR_OK;
+        }
+        if (count != base->count) DR_FAIL(h, DR_E_INVALID, "dr_load_param: '%s' has %zu elements, got %zu", name, base->count, count);
+        float* dst = h->shadow + cl.shadow_off + (base->kind == PK_MVAR ? cl.cout : 0);
+        if (rt::h2d(dst, host, count * sizeof(float), nullptr)) DR_FAIL(h, DR_E_DEVICE, "h2d failed");
+        rt::sync_stream(nullptr);
+        return DR_OK;
+    }
     if (count != p->count) DR_FAIL(h, DR_E_INVALID, "dr_load_param: '%s' has %zu elements, got %zu", name, p->count, count);
     ConvLayer& c = h->convs[p->conv];
     if (p->kind == PK_RMAX) { c.r_max = host[0]; return DR_OK; }
@@ -620,7 +653,24 @@ int dr_load_param(dr_handle* h, const char* name, const float* host, size_t coun
 int dr_read_param(dr_handle* h, const char* name, float* host, size_t count) {
     if (!h || !name || !host) return DR_E_INVALID;
     const ParamInfo* p = find_param(h, name);
-    if (!p) DR_FAIL(h, DR_E_INVALID, "dr_read_param: unknown variable '%s'", name);
+    if (!p) {
+        int slot = 0;
+        const ParamInfo* base = find_slot(h, name, &slot);
+        if (!base) DR_FAIL(h, DR_E_INVALID, "dr_read_param: unknown variable '%s'", name);
+        if (!h->cfg.training) DR_FAIL(h, DR_E_STATE, "dr_read_param: '%s' exists only on a training handle", name);
+        ConvLayer& cl = h->convs[base->conv];
+        if (slot == 2) {
+            if (count != 1) DR_FAIL(h, DR_E_INVALID, "dr_read_param: '%s' is a scalar", name);
+            host[0] = (float)cl.shadow_step;
+            return DR_OK;
+        }
+        if (count != base->count) DR_FAIL(h, DR_E_INVALID, "dr_read_param: '%s' has %zu elements, got %zu", name, base->count, count);
+        rt::sync_stream(nullptr);
+        const float* src = h->shadow + cl.shadow_off + (base->kind == PK_MVAR ? cl.cout : 0);
+        if (rt::d2h(host, src, count * sizeof(float), nullptr)) DR_FAIL(h, DR_E_DEVICE, "d2h failed");
+        rt::sync_stream(nullptr);
+        return DR_OK;
+    }
     if (count != p->count) DR_FAIL(h, DR_E_INVALID, "dr_read_param: '%s' has %zu elements, got %zu", name, p->count, count);
     ConvLayer& c = h->convs[p->conv];
     if (p->kind == PK_RMAX) { host[0] = c.r_max; return DR_OK; }
@@ -671,6 +721,35 @@ int dr_finalize_params(dr_handle* h, dr_stream stream) {
     h->finalized = true;
     h->fold_is_eval = true;
     return DR_OK;
+}
+
+// CRC-32C (Castagnoli, reflected 0x82F63B78), the checksum of TensorFlow's tensor-bundle checkpoint files; host code,
+// used by the checkpoint importer/exporter (densereg_amd/checkpoint.py) on multi-megabyte tensors.
+uint32_t dr_crc32c(uint32_t crc, const void* data, size_t n) {
+    static uint32_t table[8][256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            table[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+        ready = true;
+    }
+    const unsigned char* p = (const unsigned char*)data;
+    uint32_t c = ~crc;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+            table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    while (n--) c = table[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return ~c;
 }
 
 // ---- input front-end: handle-free, one workgroup per frame (frontend.h) --------------------------------------

@@ -131,6 +131,53 @@ class Engine:
     def conv_flops_per_crop(self) -> float:
         return self.h.conv_flops_per_crop()
 
+    # ---- checkpoints (tf.train.Saver files of the reference, train_single_gpu.py:108-123,172) -----
+    def _trainable_offsets(self):
+        off, out = 0, {}
+        for name, shape, trainable in self.h.param_infos():
+            if trainable:
+                n = int(np.prod(shape))
+                out[name] = (off, n)
+                off += n
+        return out
+
+    def adam_views(self):
+        m, v, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        self.h.call('dr_flat_adam', C.byref(m), C.byref(v), C.byref(n))
+        return _as_tensor(m.value, n.value, self.device), _as_tensor(v.value, n.value, self.device)
+
+    def load_checkpoint(self, prefix: str, strict: bool = True) -> dict:
+        """Restore from ``<prefix>.index`` / ``.data-*`` written by the reference (or by ``save_checkpoint``): model
+        variables, BatchReNorm state incl. the zero-debias slots, and -- on a training engine -- Adam's moments.
+        Returns the import report (``missing`` / ``unexpected`` names, ``scalars`` such as ``global_step``)."""
+        from . import checkpoint
+        torch.cuda.synchronize(self.device)
+        rep = checkpoint.load_into(self.h, prefix, strict=strict)
+        if self.training and (rep['adam_m'] or rep['adam_v']):
+            m, v = self.adam_views()
+            for src, dst in ((rep['adam_m'], m), (rep['adam_v'], v)):
+                for name, (off, n) in self._trainable_offsets().items():
+                    if name in src:
+                        dst[off:off + n].copy_(torch.from_numpy(src[name].reshape(-1)))
+        self.h.call('dr_finalize_params', self._stream())
+        return rep
+
+    def save_checkpoint(self, prefix: str, global_step: Optional[int] = None, beta_powers=None):
+        """Write a checkpoint the reference's ``Saver.restore`` reads by name (variables, slots, Adam moments)."""
+        from . import checkpoint
+        torch.cuda.synchronize(self.device)
+        extra = {}
+        if self.training:
+            m, v = (t.cpu().numpy() for t in self.adam_views())
+            shapes = {n: s for n, s, _ in self.h.param_infos()}
+            for name, (off, n) in self._trainable_offsets().items():
+                extra[name + '/Adam'] = m[off:off + n].reshape(shapes[name])
+                extra[name + '/Adam_1'] = v[off:off + n].reshape(shapes[name])
+            if beta_powers is not None:
+                extra['beta1_power'] = np.array(beta_powers[0], np.float32)
+                extra['beta2_power'] = np.array(beta_powers[1], np.float32)
+        return checkpoint.export_from(self.h, prefix, global_step=global_step, extra=extra)
+
 
 class _CudaArray:
     """``__cuda_array_interface__`` shim so torch can alias library-owned device memory."""

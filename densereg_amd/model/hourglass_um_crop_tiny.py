@@ -26,6 +26,7 @@ import numpy as np
 import torch
 
 from .. import flags
+from ..data import preprocess
 from ..data.evaluation import Evaluation
 from ..data.synthetic import DATASETS, make_crops
 from ..network import um_v1
@@ -132,12 +133,22 @@ def train(model: JointDetectionModel, dist=None, log=sys.stdout):
         print('[train] learning rate decays per %d steps with rate=%f' % (model.decay_steps, model.lr_decay_factor), file=log)
         print('[train] initial learning_rate = %f' % model.init_lr, file=log)
     micro = 0
-    for step in range(max_steps):
+    start_step = 0
+    if F.restore_step > 0:                                                  # train_single_gpu.py:120-123
+        rep = model.engine.load_checkpoint(os.path.join(model.train_dir, 'model.ckpt-%d' % F.restore_step))
+        start_step = F.restore_step
+        trainer.global_step = start_step                                     # lr schedule and Adam's bias correction
+        if log:
+            print('[train] restored step %d (%d unexpected names in the checkpoint)' % (start_step, len(rep['unexpected'])), file=log)
+    aug_rng = np.random.default_rng(F.seed + (dist.get_rank() if dist is not None else 0))
+    for step in range(start_step, max_steps):
         start = time.time()
         ave_loss = 0.0
         for _ in range(F.sub_batch):
             dm, poses, cfgs, coms, _n = model._dataset.batch(F.batch_size, micro)
             d_dm, d_pose, d_cfg, d_com = model._t(dm), model._t(poses), model._t(cfgs), model._t(coms)
+            if F.is_aug:                                                    # hourglass_um_crop_tiny.py:332-333
+                d_dm, d_pose = preprocess.data_aug(d_dm, d_pose, d_cfg, d_com, generator=aug_rng)
             normed = model.engine.norm_dm(d_dm, d_com)
             losses = trainer.micro_step(normed, d_pose, d_cfg, d_com, seed=micro)
             loss_value = float(losses.sum().item())
@@ -149,6 +160,10 @@ def train(model: JointDetectionModel, dist=None, log=sys.stdout):
         if log and step % 5 == 0:
             print('[model/train] %s: step %d/%d, loss = %.3f, %.3f sec/batch, %.3f sec/sample'
                   % (datetime.now(), step, max_steps, ave_loss, duration, duration / (F.batch_size * F.sub_batch)), file=log)
+        if F.save_every > 0 and ((step + 1) % F.save_every == 0 or step + 1 == max_steps):       # :170-172
+            if dist is None or dist.get_rank() == 0:
+                os.makedirs(model.train_dir, exist_ok=True)
+                model.engine.save_checkpoint(os.path.join(model.train_dir, 'model.ckpt-%d' % (step + 1)), global_step=step + 1)
     return trainer
 
 
@@ -156,6 +171,8 @@ def test_model(model: JointDetectionModel, out_path: str, log=sys.stdout):
     """test_model.test (:14-94): run the test set, write one result line per frame, return the errors."""
     F = flags.FLAGS
     total = F.num_frames or model._val_dataset.exact_num
+    if F.restore_step > 0:                                                  # test_model.py:33-34
+        model.engine.load_checkpoint(os.path.join(model.train_dir, 'model.ckpt-%d' % F.restore_step), strict=True)
     max_err, mean_err, n, step = [], [], 0, 0
     with open(out_path, 'w') as f:
         while n < total:

@@ -69,9 +69,16 @@ int dr_param_info(const dr_handle* h, int index, const char** name, int32_t dims
                   int32_t* trainable);
 int dr_load_param(dr_handle* h, const char* name, const float* host, size_t count);
 int dr_read_param(dr_handle* h, const char* name, float* host, size_t count);
+/* Both also accept, on a training handle, the zero-debias slot variables of the moving statistics that
+ * assign_moving_average keeps ([TF1.3-semantics]): "<scope>/BatchReNorm/moving_{mean,variance}/biased" (Cout
+ * floats) and ".../local_step" (1 float).  Load them AFTER the moving statistic itself (which resets them). */
 /* Pack weights for the MFMA kernels, fold eval-mode BatchReNorm; call after loading, before any
  * forward.  Synchronises. */
 int dr_finalize_params(dr_handle* h, dr_stream stream);
+
+/* CRC-32C (Castagnoli) continuation: dr_crc32c(0, data, n) for a fresh checksum.  Host code; the checksum of
+ * TensorFlow tensor-bundle checkpoints (densereg_amd/checkpoint.py). */
+uint32_t dr_crc32c(uint32_t crc, const void* data, size_t n);
 
 /* ---- input front-end: raw frame -> crop + centre of mass, augmentation ------------- */
 /* All pointers are device pointers; these three entry points need no handle (no weights, no workspace) and run
@@ -138,6 +145,9 @@ int dr_zero_grad(dr_handle* h, dr_stream stream);                       /* reset
 /* Flat fp32 views in TF trainable-variable creation order (for RCCL all-reduce / checkpoints). */
 int dr_flat_grad(dr_handle* h, float** dev_ptr, size_t* count);
 int dr_flat_param(dr_handle* h, float** dev_ptr, size_t* count);
+/* Adam's first / second moment estimates, same layout as the flat parameter buffer (TF slot variables
+ * "<var>/Adam" and "<var>/Adam_1"; checkpoint import/export, resume). */
+int dr_flat_adam(dr_handle* h, float** m_dev_ptr, float** v_dev_ptr, size_t* count);
 /* g = clip(acc / div, -clip, clip); Adam(beta1=0.5, beta2=0.999, eps=1e-8), TF update rule;
  * step is 1-based (train_single_gpu.py:86-89; hourglass_um_crop_tiny.py:436-439).  Re-packs the
  * weights for the next forward. */

@@ -1,0 +1,175 @@
+"""TF-1.3 V2 checkpoint import / export (``densereg_amd/checkpoint.py``).
+
+No checkpoint written by the reference exists here (TensorFlow cannot be installed), so the format is pinned three
+ways: known answers of its primitives (CRC-32C check value, masked CRC, varints, snappy), a table assembled BY HAND in
+this file from the published block / footer layout (independent of the writer), and writer <-> reader round trips
+including corruption detection.  The last tests drive the engine: export -> restore -> identical variables, slot
+variables and Adam moments, and the reference's variable naming (scope repeated for the zero-debias slots).
+"""
+import struct
+
+import numpy as np
+import pytest
+
+from densereg_amd import checkpoint as ck
+
+
+def test_crc32c_and_mask_known_answers():
+    assert ck.crc32c(b'123456789') == 0xE3069283            # the CRC-32C check value
+    assert ck.crc32c(b'') == 0
+    assert ck.crc32c(bytes(32)) == 0x8A9136AA                # rfc3720 B.4: 32 bytes of zeros
+    assert ck.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43       # rfc3720 B.4: 32 bytes of ones
+    big = bytes(range(256)) * 64                             # > 4 KB: goes through the library
+    assert ck.crc32c(big) == ck._crc_py(big)
+    assert ck.crc32c(big[100:], ck.crc32c(big[:100])) == ck.crc32c(big)      # continuation
+    for c in (0, 1, 0xE3069283, 0xFFFFFFFF):
+        assert ck.unmask_crc(ck.mask_crc(c)) == c
+    assert ck.mask_crc(0) == 0xa282ead8
+
+
+def test_varints_and_entry_proto():
+    for n, b in ((0, b'\x00'), (1, b'\x01'), (127, b'\x7f'), (128, b'\x80\x01'), (300, b'\xac\x02'), (2 ** 32, b'\x80\x80\x80\x80\x10')):
+        assert ck.put_varint(n) == b
+        assert ck.get_varint(b, 0) == (n, len(b))
+    # BundleEntryProto by hand: dtype DT_FLOAT(1), shape [3,4], offset 64, size 48, crc fixed32
+    raw = (b'\x08\x01' + b'\x12\x08' + b'\x12\x02\x08\x03' + b'\x12\x02\x08\x04' + b'\x20\x40' + b'\x28\x30' +
+           b'\x35' + struct.pack('<I', 0xDEADBEEF))
+    e = ck.parse_entry(raw)
+    assert (e['dtype'], e['shape'], e['offset'], e['size'], e['crc32c']) == (1, [3, 4], 64, 48, 0xDEADBEEF)
+    assert ck.build_entry(1, (3, 4), 64, 48, 0xDEADBEEF) == raw
+    assert ck.parse_entry(ck.build_entry(3, (), 0, 4, 7))['shape'] == []
+
+
+def test_snappy_known_vector():
+    # literal "abcd" (tag 0x0c = len 4), then copy len 8 offset 4 (1-byte-offset form: tag 0b000_100_01 = 0x11, off 4)
+    comp = b'\x0c' + b'\x0c' + b'abcd' + b'\x11\x04'
+    assert ck.snappy_decompress(comp) == b'abcdabcdabcd'
+    with pytest.raises(ck.CheckpointError):
+        ck.snappy_decompress(b'\x05' + b'\x0c' + b'abcd')
+
+
+def _hand_table(tmp_path):
+    """An SSTable written out byte by byte from the format description (table/format.cc, block.cc)."""
+    def block(body):
+        return body + b'\x00' + struct.pack('<I', ck.mask_crc(ck.crc32c(body + b'\x00')))
+    # data block: keys "" , "Conv/biases", "Conv/weights" (shares the 5-byte prefix "Conv/")
+    ents = (b'\x00\x00\x02' + b'' + b'h0' +
+            b'\x00\x0b\x02' + b'Conv/biases' + b'v1' +
+            b'\x05\x07\x02' + b'weights' + b'v2')
+    data = ents + struct.pack('<I', 0) + struct.pack('<I', 1)
+    f = block(data)
+    meta_off = len(f)
+    meta = struct.pack('<I', 0) + struct.pack('<I', 1)
+    f += block(meta)
+    idx_off = len(f)
+    handle = ck.put_varint(0) + ck.put_varint(len(data))
+    idx = b'\x00\x0c' + ck.put_varint(len(handle)) + b'Conv/weights' + handle + struct.pack('<I', 0) + struct.pack('<I', 1)
+    f += block(idx)
+    footer = ck.put_varint(meta_off) + ck.put_varint(len(meta)) + ck.put_varint(idx_off) + ck.put_varint(len(idx))
+    footer += b'\x00' * (40 - len(footer)) + struct.pack('<Q', 0xdb4775248b80fb57)
+    p = tmp_path / 'hand.index'
+    p.write_bytes(f + footer)
+    return p
+
+
+def test_reader_on_hand_assembled_table(tmp_path):
+    p = _hand_table(tmp_path)
+    assert ck.read_table(str(p)) == [(b'', b'h0'), (b'Conv/biases', b'v1'), (b'Conv/weights', b'v2')]
+    raw = bytearray(p.read_bytes())
+    raw[10] ^= 1
+    p.write_bytes(bytes(raw))
+    with pytest.raises(ck.CheckpointError, match='checksum'):
+        ck.read_table(str(p))
+    assert ck.read_table(str(p), verify=False)[1][0] != b'Conv/biases' or True      # unverified read does not raise
+    raw[-1] ^= 0xFF
+    p.write_bytes(bytes(raw))
+    with pytest.raises(ck.CheckpointError, match='magic'):
+        ck.read_table(str(p))
+
+
+def test_writer_reader_round_trip_multi_block(tmp_path):
+    rng = np.random.default_rng(0)
+    tensors = {'Conv_%d/BatchReNorm/%s' % (i, k): rng.standard_normal(rng.integers(1, 40)).astype(np.float32)
+               for i in range(120) for k in ('beta', 'gamma', 'moving_mean')}
+    tensors['hg_imgproc/Conv/weights'] = rng.standard_normal((7, 7, 1, 32)).astype(np.float32)
+    tensors['global_step'] = np.array(12345, np.int32)
+    tensors['step64'] = np.array([2 ** 40, -3], np.int64)
+    tensors['empty'] = np.zeros((0, 4), np.float32)
+    tensors['flags'] = np.array([True, False, True])
+    prefix = str(tmp_path / 'model.ckpt-7')
+    ck.write_checkpoint(prefix, tensors)
+    back = ck.read_checkpoint(prefix)
+    assert sorted(back) == sorted(tensors)
+    for k in tensors:
+        assert back[k].dtype == tensors[k].dtype and back[k].shape == tensors[k].shape
+        np.testing.assert_array_equal(back[k], tensors[k])
+    # several data blocks (small block size) read back the same
+    items = [(b'', ck.build_header())] + [(('k%04d' % i).encode(), bytes([i % 251]) * (i % 17)) for i in range(500)]
+    ck.write_table(str(tmp_path / 't.index'), items, block_size=256)
+    assert ck.read_table(str(tmp_path / 't.index')) == items
+    # subset read, missing name, corrupt tensor bytes
+    assert list(ck.read_checkpoint(prefix, names=['global_step'])) == ['global_step']
+    with pytest.raises(ck.CheckpointError, match='not in checkpoint'):
+        ck.read_checkpoint(prefix, names=['nope'])
+    data = prefix + '.data-00000-of-00001'
+    raw = bytearray(open(data, 'rb').read())
+    raw[len(raw) // 2] ^= 0x10
+    open(data, 'wb').write(bytes(raw))
+    with pytest.raises(ck.CheckpointError, match='tensor checksum'):
+        ck.read_checkpoint(prefix)
+    assert len(ck.read_checkpoint(prefix, verify=False)) == len(tensors)
+
+
+def test_engine_export_restore_round_trip(emu, tmp_path):
+    """Engine (training handle) -> checkpoint with the reference's names -> fresh handle: every variable, the
+    zero-debias slots and their step counter come back bit-exact; unknown / missing names are reported."""
+    from oracle import net
+    from oracle.graph import NetConfig, param_specs
+    cfg = NetConfig(1, 8, 2)
+    rng = np.random.default_rng(1)
+    params = net.init_params(cfg, seed=3)
+    for k in params:
+        if params[k].dtype == np.float32 and params[k].size > 1:
+            params[k] = rng.standard_normal(params[k].shape).astype(np.float32)
+        if k.endswith('moving_variance'):
+            params[k] = np.abs(params[k]) + 0.5
+    h = emu.handle(cfg, 1, training=True)
+    h.load_params(params)
+    # give one layer non-trivial slot state, as after a few training steps
+    name = 'Conv_2/BatchReNorm/moving_mean'
+    n = int(np.prod(dict((a, b) for a, b, _ in h.param_infos())[name]))
+    biased = rng.standard_normal(n).astype(np.float32)
+    import ctypes as C
+    h.call('dr_load_param', (name + '/biased').encode(), biased.ctypes.data, n)
+    h.call('dr_load_param', (name + '/local_step').encode(), np.array([7], np.float32).ctypes.data, 1)
+    prefix = str(tmp_path / 'model.ckpt-40')
+    names = ck.export_from(h, prefix, global_step=40)
+    assert 'global_step' in names and 'Conv_2/BatchReNorm/Conv_2/BatchReNorm/moving_mean/biased' in names
+    tensors = ck.read_checkpoint(prefix)
+    assert [n for n, _, _ in param_specs(cfg)] == [n for n in [p[0] for p in h.param_infos()]]
+    # what a reference checkpoint additionally holds: Adam slots and the beta powers
+    tensors['Conv/weights/Adam'] = np.zeros_like(tensors['Conv/weights'])
+    tensors['Conv/weights/Adam_1'] = np.ones_like(tensors['Conv/weights'])
+    tensors['beta1_power'] = np.array(0.5 ** 8, np.float32)
+    tensors['some/other/variable'] = np.zeros(3, np.float32)
+    ck.write_checkpoint(prefix, tensors)
+    h2 = emu.handle(cfg, 1, training=True)
+    rep = ck.load_into(h2, prefix)
+    assert rep['missing'] == [] and rep['unexpected'] == ['some/other/variable']
+    assert list(rep['adam_m']) == ['Conv/weights'] and float(rep['scalars']['beta1_power']) == 0.5 ** 8
+    a, b = h.read_params(), h2.read_params()
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    got = np.empty(n, np.float32)
+    h2.call('dr_read_param', (name + '/biased').encode(), got.ctypes.data, n)
+    np.testing.assert_array_equal(got, biased)
+    step = np.empty(1, np.float32)
+    h2.call('dr_read_param', (name + '/local_step').encode(), step.ctypes.data, 1)
+    assert step[0] == 7.0
+    # a checkpoint that lacks a model variable is refused in strict mode
+    del tensors['Conv/weights']
+    ck.write_checkpoint(prefix, tensors)
+    with pytest.raises(ck.CheckpointError, match='lacks'):
+        ck.load_into(emu.handle(cfg, 1, training=True), prefix)
+    assert 'Conv/weights' in ck.load_into(emu.handle(cfg, 1, training=True), prefix, strict=False)['missing']
+    h.close(); h2.close()

@@ -92,3 +92,64 @@ def test_cli_test_and_train_drivers_on_gpu(gpu, tmp_path, monkeypatch):
     assert trainer.global_step == 2
     assert any(np.abs(after[k] - before[k]).max() > 0 for k in before if k.endswith('weights'))
     flags.parse([])
+
+
+@pytest.mark.gpu
+def test_engine_checkpoint_round_trip_with_adam(gpu, tmp_path):
+    """Engine.save_checkpoint / load_checkpoint (TF V2 files with the reference's names): after two optimizer
+    steps, a fresh engine restored from the files continues bit-identically (variables, BatchReNorm slots, Adam)."""
+    import torch
+    from densereg_amd import checkpoint as ck
+    from densereg_amd.data.synthetic import make_crops
+    from densereg_amd.engine import Engine
+    from densereg_amd.parallel import DataParallelTrainer
+    B = 4
+    dm, poses, cfgs, coms, _ = make_crops(B, 'nyu', seed=3)
+
+    def fresh():
+        e = Engine(num_stack=1, num_fea=32, num_jnt=14, max_batch=B, training=True)
+        rng = np.random.default_rng(7)
+        params = {}
+        for name, shape, _ in e.param_infos():
+            leaf = name.rsplit('/', 1)[1]
+            if leaf == 'weights':
+                fan = int(np.prod(shape[:3]))
+                params[name] = (rng.standard_normal(shape) * np.sqrt(2.0 / fan)).astype(np.float32)
+            elif leaf in ('gamma', 'moving_variance', 'r_max'):
+                params[name] = np.ones(shape, np.float32)
+            else:
+                params[name] = np.zeros(shape, np.float32)
+        e.load_params(params)
+        return e
+
+    t = [torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda() for a in (dm, poses, cfgs, coms)]
+
+    def steps(e, trainer, n):
+        normed = e.norm_dm(t[0], t[3])
+        for i in range(n):
+            trainer.micro_step(normed, t[1], t[2], t[3], seed=i, dropout_mode=0)
+        torch.cuda.synchronize()
+
+    a = fresh()
+    ta = DataParallelTrainer(a, 'nyu', sub_batch=1)
+    steps(a, ta, 2)
+    prefix = str(tmp_path / 'model.ckpt-2')
+    names = a.save_checkpoint(prefix, global_step=2)
+    assert 'hg_imgproc/Conv/weights/Adam_1' in names and 'global_step' in names
+    assert int(ck.read_checkpoint(prefix, names=['global_step'])['global_step']) == 2
+    b = fresh()
+    rep = b.load_checkpoint(prefix)
+    assert rep['missing'] == [] and rep['unexpected'] == []
+    tb = DataParallelTrainer(b, 'nyu', sub_batch=1)
+    tb.global_step = 2
+    pa, pb = a.read_params(), b.read_params()
+    for k in pa:
+        np.testing.assert_array_equal(pa[k], pb[k], err_msg=k)
+    steps(a, ta, 1)
+    steps(b, tb, 1)
+    pa, pb = a.read_params(), b.read_params()
+    worst = max(float(np.abs(pa[k] - pb[k]).max() / (np.abs(pa[k]).max() + 1e-12)) for k in pa)
+    # same state in, same step out -- up to the order of the few fp atomics left on the path (max-pool backward
+    # scatter, stem moments, loss sums): measured 1.3e-6 of a tensor's max
+    assert worst < 1e-5, worst
+    a.close(); b.close()

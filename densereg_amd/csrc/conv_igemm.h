@@ -65,7 +65,10 @@ struct ConvTile {
     static constexpr int kBK = BK_;
     static constexpr int kThreads = 256;
     static constexpr int kSK = BK_;               // LDS row stride (floats) of both operand tiles: unpadded, swizzled
-    static_assert(BK_ == 16, "the slot swizzle below assumes four 16-byte slots per row");
+    static_assert(BK_ == 16 || BK_ == 64, "slot swizzles exist for 4 and 16 slots per row");
+    // float offset to XOR into a row's k index: 4 slots -> slot ^ ((row>>2)&3); 16 slots (a 256-byte row = one full
+    // bank row, so the 16 rows of a ds_read_b128 lane group must land on 16 different slots) -> slot ^ (row&15)
+    __host__ __device__ static constexpr int swz(int row) { return BK_ == 16 ? (row & 12) : ((row & 15) << 2); }
     static constexpr int kWTM = BM / WM;          // wave tile rows
     static constexpr int kWTN = BN / WN;
     static constexpr int kTM = kWTM / 32;
@@ -84,11 +87,15 @@ struct ConvTile {
 // 640 row blocks of 64: with Np = 256 / 512 that is exactly 5 / 10 workgroups per CU, so five resident
 // workgroups finish in whole rounds, while four leave a last round with one lonely workgroup per CU whose
 // load latency nothing hides (measured: a quarter of the kernel time).
-template <int BM, int BN>
-constexpr int conv_min_waves() { return BM * BN >= 128 * 128 ? 3 : 5; }
+//
+// BK_ = 64 ("fat K-tile") is the variant for grids that cannot fill the chip (everything below 32x32): such a launch
+// is a serial chain of K-tiles at ~0.6 us each (load -> LDS -> barrier -> MFMA, one wave per SIMD, nothing to hide
+// behind), so it moves four 16-channel chunks per round trip -- a 3x3 64->64 layer is 9 iterations instead of 36.
+template <int BM, int BN, int BK_>
+constexpr int conv_min_waves() { return BK_ == 64 ? 2 : (BM * BN >= 128 * 128 ? 3 : 5); }
 
 template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16>
-__global__ __launch_bounds__(256, (conv_min_waves<BM, BN>())) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_igemm_kernel(const ConvParams p) {
     using T = ConvTile<BM, BN, WM, WN, BK_>;
     constexpr int BK = T::kBK;
     constexpr int SK = T::kSK;
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN>())) void conv_igemm_ke
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int taps = p.ksize * p.ksize;
-    const int KT = p.Kp / BK;
+    const int KT = (p.Kp + BK - 1) / BK;
     const int T_total = taps * KT;
     const int pad = p.ksize / 2;
 
@@ -117,6 +124,11 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN>())) void conv_igemm_ke
     int a_row[T::kAIters], a_k4[T::kAIters];
     unsigned a_off[T::kAIters];       // element offset of (pixel m, channel 4*k4) relative to p.x
     unsigned a_taps[T::kAIters];      // bit t: tap t reads a valid pixel for this row
+    // image sides are powers of two on this network: shifts instead of three integer divisions per row; the tap
+    // mask is assembled branch-free from "has a row above / below, a column left / right" (this prologue runs
+    // in every workgroup and was ~2 us of dependent integer code per owned row)
+    const bool pow2 = (p.W & (p.W - 1)) == 0 && (HW & (HW - 1)) == 0;
+    const int w_shift = __builtin_ctz((unsigned)p.W);
 #pragma unroll
     for (int i = 0; i < T::kAIters; ++i) {
         const int idx = tid + i * T::kThreads;
@@ -126,31 +138,41 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN>())) void conv_igemm_ke
         const int m = m0 + row;
         bool ok = m < M;
         if (ok && p.rowmask) ok = !(p.rowmask[m] < p.mask_thresh);
-        const int rem = ok ? (m % HW) : 0;
-        const int y = rem / p.W, x = rem % p.W;
-        unsigned mask = 0;
-        if (ok) {
-            int t = 0;                                     // no div/mod by the runtime ksize in here
-            for (int dy = -pad; dy <= pad; ++dy)
-                for (int dx = -pad; dx <= pad; ++dx, ++t) {
-                    const int yy = y + dy, xx = x + dx;
-                    if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1u << t;
-                }
+        const int mm = ok ? m : 0;
+        int y, x;
+        if (pow2) {
+            const int rem = mm & (HW - 1);
+            y = rem >> w_shift; x = rem & (p.W - 1);
+        } else {
+            const int rem = mm % HW;
+            y = rem / p.W; x = rem % p.W;
         }
-        a_taps[i] = mask;
+        unsigned mask = 1u;
+        if (p.ksize == 3) {
+            const unsigned cols = (x > 0 ? 1u : 0u) | 2u | (x < p.W - 1 ? 4u : 0u);
+            mask = (y > 0 ? cols : 0u) | (cols << 3) | (y < p.H - 1 ? cols << 6 : 0u);
+        }
+        a_taps[i] = ok ? mask : 0u;
         a_off[i] = ok ? (unsigned)((long)m * p.x_cs + p.x_coff + a_k4[i] * 4) : 0u;
     }
-    // weight tile: thread -> (output channel row, 4 consecutive k); at most two float4 per thread (BN = 128).
-    // Scalars, not arrays: hipcc kept two-element arrays in scratch once the K loop was unrolled by two.
-    static_assert(T::kBIters <= 2, "B loader handles at most two float4 per thread");
-    const int b_row0 = tid / (BK / 4), b_row1 = (tid + T::kThreads) / (BK / 4), b_k4 = tid % (BK / 4);
+    // weight tile.  BK = 16: thread -> (output channel row, 4 consecutive k), at most two float4 per thread (BN =
+    // 128); scalars, not arrays: hipcc kept two-element arrays in scratch once the K loop was unrolled by two.
+    // BK = 64: the tile is four 16-channel chunks, each a contiguous [BN][16] block of the packed weights; iteration
+    // i of a thread IS chunk i (256 threads = 64 rows x 4 k4), so one row / k4 / offset serves all four.
+    static_assert(BK == 64 ? (BN == 64) : (T::kBIters <= 2), "B loader mapping");
+    constexpr int BKC = 16;                                                 // packing granularity of the weights
+    const int b_row0 = tid / (BKC / 4), b_row1 = (tid + T::kThreads) / (BKC / 4), b_k4 = tid % (BKC / 4);
     const bool b_ok0 = b_row0 < BN && n0 + b_row0 < p.Np;
-    const bool b_ok1 = T::kBIters > 1 && b_row1 < BN && n0 + b_row1 < p.Np;
-    const unsigned b_off0 = (unsigned)((n0 + b_row0) * BK + b_k4 * 4);      // = n0*BK + 4*tid: fully coalesced
-    const unsigned b_off1 = (unsigned)((n0 + b_row1) * BK + b_k4 * 4);
+    const bool b_ok1 = BK == 16 && T::kBIters > 1 && b_row1 < BN && n0 + b_row1 < p.Np;
+    const unsigned b_off0 = (unsigned)((n0 + b_row0) * BKC + b_k4 * 4);     // = n0*16 + 4*tid: fully coalesced
+    const unsigned b_off1 = (unsigned)((n0 + b_row1) * BKC + b_k4 * 4);
+    const long w_chunk = (long)taps * p.Np * BKC;                           // floats between consecutive chunks of a tap
+    const int n_chunks = p.Kp / BKC;
 
     float4 a_reg[T::kAIters];
     float4 b_reg0, b_reg1;
+    float4 b_fat0, b_fat1, b_fat2, b_fat3;                                 // BK = 64: one float4 per chunk (named: a
+                                                                           // float4[4] here was promoted to LDS by hipcc)
 
     // Refill = UNCONDITIONAL loads: a predicated-off lane reads 16 B of zeros from p.zeros (pointer select,
     // no branch).  With "v = 0; if (ok) v = load" hipcc copies the loaded value at the join and parks an
@@ -176,8 +198,17 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN>())) void conv_igemm_ke
             a_reg[i] = *reinterpret_cast<const float4*>(src);
             a_nv[i] = ok ? nv : 4;                                          // zeros need no masking
         }
-        b_reg0 = *reinterpret_cast<const float4*>(b_ok0 ? ld_w + b_off0 : p.zeros);
-        if constexpr (T::kBIters > 1) b_reg1 = *reinterpret_cast<const float4*>(b_ok1 ? ld_w + b_off1 : p.zeros);
+        if constexpr (BK == 16) {
+            b_reg0 = *reinterpret_cast<const float4*>(b_ok0 ? ld_w + b_off0 : p.zeros);
+            if constexpr (T::kBIters > 1) b_reg1 = *reinterpret_cast<const float4*>(b_ok1 ? ld_w + b_off1 : p.zeros);
+        } else {
+            const int left = n_chunks - ld_kc / BKC;                        // the last chunk group may be short
+            const float* w0 = ld_w + b_off0;
+            b_fat0 = *reinterpret_cast<const float4*>(b_ok0 && left > 0 ? w0 : p.zeros);
+            b_fat1 = *reinterpret_cast<const float4*>(b_ok0 && left > 1 ? w0 + w_chunk : p.zeros);
+            b_fat2 = *reinterpret_cast<const float4*>(b_ok0 && left > 2 ? w0 + 2 * w_chunk : p.zeros);
+            b_fat3 = *reinterpret_cast<const float4*>(b_ok0 && left > 3 ? w0 + 3 * w_chunk : p.zeros);
+        }
         // advance the cursor: taps innermost.  The nine taps of one 16-channel chunk re-read the same 64-byte
         // pixel slices (shifted by a pixel), one K-tile apart, so they hit in L1/L2; with the channel sweep
         // innermost the re-read came 16 K-tiles later, after the slice had left this XCD's 4 MB L2.
@@ -189,7 +220,8 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN>())) void conv_igemm_ke
             ld_kc += BK;
         }
         ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;
-        ld_w += p.Np * BK;                                                 // packed in exactly this order
+        if constexpr (BK == 16) ld_w += p.Np * BKC;                        // packed in exactly this order
+        else ld_w = p.w + ((long)(ld_kc / BKC) * taps + ld_tap) * p.Np * BKC;
     };
     auto store_tile = [&](const int buf, bool was_tail) __attribute__((always_inline)) {
 #pragma unroll
@@ -202,21 +234,37 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN>())) void conv_igemm_ke
                 v.z = nv > 2 ? v.z : 0.f;
                 v.w = nv > 3 ? v.w : 0.f;
             }
-            *reinterpret_cast<float4*>(&As[buf][r][k ^ ((r & 12))]) = v;      // slot k4 ^ ((r>>2)&3), in floats
+            *reinterpret_cast<float4*>(&As[buf][r][k ^ T::swz(r)]) = v;          // swizzled 16-byte slot
         }
-        if (b_row0 < BN) *reinterpret_cast<float4*>(&Bs[buf][b_row0][(b_k4 * 4) ^ (b_row0 & 12)]) = b_reg0;
-        if constexpr (T::kBIters > 1) {
-            if (b_row1 < BN) *reinterpret_cast<float4*>(&Bs[buf][b_row1][(b_k4 * 4) ^ (b_row1 & 12)]) = b_reg1;
+        if constexpr (BK == 16) {
+            if (b_row0 < BN) *reinterpret_cast<float4*>(&Bs[buf][b_row0][(b_k4 * 4) ^ T::swz(b_row0)]) = b_reg0;
+            if constexpr (T::kBIters > 1) {
+                if (b_row1 < BN) *reinterpret_cast<float4*>(&Bs[buf][b_row1][(b_k4 * 4) ^ T::swz(b_row1)]) = b_reg1;
+            }
+        } else {
+            float* brow = &Bs[buf][b_row0][0];
+            const int sw = T::swz(b_row0), kq = b_k4 * 4;
+            *reinterpret_cast<float4*>(brow + ((0 * BKC + kq) ^ sw)) = b_fat0;
+            *reinterpret_cast<float4*>(brow + ((1 * BKC + kq) ^ sw)) = b_fat1;
+            *reinterpret_cast<float4*>(brow + ((2 * BKC + kq) ^ sw)) = b_fat2;
+            *reinterpret_cast<float4*>(brow + ((3 * BKC + kq) ^ sw)) = b_fat3;
         }
     };
 
-    dr_f32x16 acc[T::kTM][T::kTN];
+    // A wave that owns a single 32x32 output tile would run ONE chain of dependent MFMAs (each waits for the
+    // previous result: ~150 cycles instead of the 64-cycle issue rate, and on a grid that leaves one wave per SIMD
+    // nothing fills the gap).  Such tiles accumulate alternate k-steps into KACC independent accumulators that are
+    // summed, in a fixed order, after the K loop.
+    constexpr int KACC = (T::kTM * T::kTN == 1) ? (BK == 64 ? 4 : 2) : 1;
+    dr_f32x16 accp[KACC][T::kTM][T::kTN];
 #pragma unroll
-    for (int i = 0; i < T::kTM; ++i)
+    for (int q = 0; q < KACC; ++q)
 #pragma unroll
-        for (int j = 0; j < T::kTN; ++j)
+        for (int i = 0; i < T::kTM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < T::kTN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accp[q][i][j][r] = 0.f;
 
     bool tail0 = BK > p.Cin;
     load_tile();
@@ -238,10 +286,10 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN>())) void conv_igemm_ke
         for (int g = 0; g < BK / 8; ++g) {
 #pragma unroll
             for (int i = 0; i < T::kTM; ++i)
-                a4[g][i] = *reinterpret_cast<const float4*>(&As[buf][wm * T::kWTM + i * 32 + li][(g * 8 + lk * 4) ^ (li & 12)]);
+                a4[g][i] = *reinterpret_cast<const float4*>(&As[buf][wm * T::kWTM + i * 32 + li][(g * 8 + lk * 4) ^ T::swz(li)]);
 #pragma unroll
             for (int j = 0; j < T::kTN; ++j)
-                b4[g][j] = *reinterpret_cast<const float4*>(&Bs[buf][wn * T::kWTN + j * 32 + li][(g * 8 + lk * 4) ^ (li & 12)]);
+                b4[g][j] = *reinterpret_cast<const float4*>(&Bs[buf][wn * T::kWTN + j * 32 + li][(g * 8 + lk * 4) ^ T::swz(li)]);
         }
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g)
@@ -253,11 +301,12 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN>())) void conv_igemm_ke
                     for (int j = 0; j < T::kTN; ++j) {
                         const float av = s4 == 0 ? a4[g][i].x : s4 == 1 ? a4[g][i].y : s4 == 2 ? a4[g][i].z : a4[g][i].w;
                         const float bv = s4 == 0 ? b4[g][j].x : s4 == 1 ? b4[g][j].y : s4 == 2 ? b4[g][j].z : b4[g][j].w;
-                        if (ABL == 2) acc[i][j][0] = fmaf(av, bv, acc[i][j][0]);
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                        const int q = (g * 4 + s4) % KACC;                  // compile-time after unrolling
+                        if (ABL == 2) accp[q][i][j][0] = fmaf(av, bv, accp[q][i][j][0]);
+                        else accp[q][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accp[q][i][j], 0, 0, 0);
                     }
         if (ABL == 4) {
-            if (more) abl_sink += a_reg[0].x + b_reg0.x + (T::kBIters > 1 ? b_reg1.x : 0.f);
+            if (more) abl_sink += a_reg[0].x + (BK == 16 ? b_reg0.x + (T::kBIters > 1 ? b_reg1.x : 0.f) : b_fat0.x);
         } else if (more) {
             store_tile(buf ^ 1, was_tail);
         }
@@ -271,6 +320,15 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN>())) void conv_igemm_ke
         k_tile(1, t + 2 < T_total);
     }
     if (T_total & 1) k_tile(0, false);
+    dr_f32x16 acc[T::kTM][T::kTN];
+#pragma unroll
+    for (int i = 0; i < T::kTM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::kTN; ++j) {
+            acc[i][j] = accp[0][i][j];
+#pragma unroll
+            for (int q = 1; q < KACC; ++q) acc[i][j] += accp[q][i][j];
+        }
     if (ABL == 4 && abl_sink == 12345.678f) p.y[0] = abl_sink;
 
     // ---- epilogue ----------------------------------------------------------------------------

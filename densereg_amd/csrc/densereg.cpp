@@ -45,11 +45,11 @@ static inline int grid_for(long total, int block = 256, int cap = 256 * 8) {
 // ==============================================================================================
 namespace dr {
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = 16>
 static void launch_cfg(const ConvParams& p, hipStream_t s) {
     const int M = p.B * p.H * p.W;
     dim3 grid(dr_ceil_div(M, BM), dr_ceil_div(p.Np, BN));
-    DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, p);
+    DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK>), grid, dim3(256), 0, s, p);
 }
 
 static int g_force_tile = -1;        // test/bench hook (dr_dbg_conv_bench); -1 = heuristic
@@ -64,6 +64,10 @@ int conv_tile_id(const ConvParams& p) {
     // tile (1280 workgroups) wins by 5-12 % despite re-reading A twice (3x3 128->128: 141 vs 150 us).
     auto balance = [](long blocks) { return (double)blocks / (double)(dr_ceil_div((int)blocks, 256) * 256); };
     const long rows64 = dr_ceil_div(M, 64), rows128 = dr_ceil_div(M, 128);
+    // Grids that leave CUs idle (everything below 32x32 at B=40) are chains of ~0.6 us K-tiles with nothing to
+    // overlap: the fat K-tile variant moves 64 channels per round trip (3x3 64->64 at 8x8: 22.8 -> see
+    // profiles/r01_conv_microbench.md).  Needs >= 2 fat tiles to pay for its larger prologue.
+    if (p.Np % 64 == 0 && rows64 * (p.Np / 64) <= 256 && (long)p.ksize * p.ksize * p.Kp >= 128) return KID_CONV_64x64_K64;
     if (p.Np % 128 == 0) {
         const long b128 = rows128 * (p.Np / 128), b64x128 = rows64 * (p.Np / 128), b64x64 = rows64 * (p.Np / 64);
         if (b128 >= 4096) return KID_CONV_128x128;
@@ -78,7 +82,7 @@ int conv_tile_id(const ConvParams& p) {
 int conv_stat_rows(const ConvParams& p) {
     const int M = p.B * p.H * p.W;
     const int t = conv_tile_id(p);
-    return dr_ceil_div(M, (t == KID_CONV_64x128 || t == KID_CONV_64x64) ? 64 : 128);
+    return dr_ceil_div(M, (t == KID_CONV_64x128 || t == KID_CONV_64x64 || t == KID_CONV_64x64_K64) ? 64 : 128);
 }
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
@@ -92,6 +96,7 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         case KID_CONV_64x128: launch_cfg<64, 128, 2, 2>(p, s); break;
         case KID_CONV_128x64: launch_cfg<128, 64, 2, 2>(p, s); break;
         case KID_CONV_64x64: launch_cfg<64, 64, 2, 2>(p, s); break;
+        case KID_CONV_64x64_K64: launch_cfg<64, 64, 2, 2, 64>(p, s); break;
         default: launch_cfg<128, 32, 4, 1>(p, s); break;
     }
     return 0;
@@ -1246,7 +1251,7 @@ extern "C" int dr_dbg_mfma_peak(int iters, int waves_per_simd, int zero_data, fl
 
 // force the conv tile choice of every following launch (-1 = heuristic); tests sweep all tile shapes with it
 extern "C" int dr_dbg_force_tile(int tile) {
-    if (tile < -1 || tile > KID_CONV_128x32) return DR_E_INVALID;
+    if (tile < -1 || tile > KID_CONV_64x64_K64) return DR_E_INVALID;
     g_force_tile = tile;
     return DR_OK;
 }

@@ -75,11 +75,11 @@ def test_conv_golden_vectors(be):
         assert _rel(y, g['y%d' % i]) < 2e-5
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5])
 def test_conv_every_tile_shape(be, tile):
     """Each tile configuration of the implicit-GEMM kernel (the heuristic only exercises some per shape)."""
     rng = np.random.default_rng(tile)
-    np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32}[tile]
+    np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32, 5: 64}[tile]          # 5 = 64x64 tile with the fat (BK = 64) K-tile
     Cout, Cin, k = np_needed - 3, 37, 3
     x = rng.standard_normal((1, 9, 15, Cin)).astype(np.float32)          # 135 rows: ragged last M tile
     w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
@@ -91,8 +91,9 @@ def test_conv_every_tile_shape(be, tile):
         be.lib.dr_dbg_force_tile(-1)
     yr, _ = ref_conv2d(x, w, None, shift, True)
     assert _rel(y, yr) < 2e-5
-    # one and two K-tiles (1x1, Cin = 12 and 20): the unrolled-by-two loop with an odd tail
-    for cin in (12, 20):
+    # one and two K-tiles (1x1, Cin = 12 and 20): the unrolled-by-two loop with an odd tail; 70 / 130 channels:
+    # a short last chunk group of the fat K-tile
+    for cin in (12, 20, 70, 130):
         x1 = rng.standard_normal((2, 4, 5, cin)).astype(np.float32)
         w1 = rng.standard_normal((1, 1, cin, Cout)).astype(np.float32)
         try:

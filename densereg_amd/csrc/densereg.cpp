@@ -494,8 +494,12 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
     alloc_f(h->scratch, h->n_scratch);
     h->scratch_l[0] = h->scratch;
     {
+        // Lanes are opt-in (DR_MULTI_STREAM=1): measured on MI355X after the small-grid kernels were tightened, the
+        // event edges cost more than the overlap returns at every batch size (B=40: train equal, inference -1 %;
+        // B=1: -11 %: such steps are bound by the host's launch rate, and every edge is two more API calls).
+        const char* multi = getenv("DR_MULTI_STREAM");
         const char* single = getenv("DR_SINGLE_STREAM");
-        h->multi_stream = !(single && single[0] == '1');
+        h->multi_stream = multi && multi[0] == '1' && !(single && single[0] == '1');
     }
     for (int l = 1; l < h->n_lanes; ++l) {
         h->lane_stream[l] = rt::stream_create();

@@ -130,7 +130,7 @@ struct dr_handle {
     hipStream_t lane_stream[dr::DR_MAX_LANES] = {};         // [0] unused: lane 0 is the caller's stream
     std::vector<dr::rt::Event> lane_ev;                     // one ordering event per FORK / JOIN op
     int n_lanes = 1;
-    bool multi_stream = true;                              // DR_SINGLE_STREAM=1 or profiling: every lane = caller's stream
+    bool multi_stream = false;                             // DR_MULTI_STREAM=1 turns the lanes on; off or profiling: every lane = caller's stream
     float* tiny = nullptr;                                  // (B,h,w) normalised depth at map resolution
     float* tiny_ext = nullptr;                              // same, for dr_vote on external maps
     float* zeros = nullptr;                                 // 256 B of zeros: target of predicated-off loads

@@ -113,7 +113,7 @@ def test_train_step_config3_nyu_two_stacks_dropout_mask(gpu):
 @pytest.mark.gpu
 def test_lanes_match_single_stream(gpu, monkeypatch):
     """The executor runs the two branches of every hourglass level on separate HIP streams (net.h: lanes).
-    Five training micro-steps + an eval forward with lanes on must reproduce a DR_SINGLE_STREAM=1 handle: maps
+    Five training micro-steps + an eval forward with lanes on (DR_MULTI_STREAM=1) must reproduce the default single-stream handle: maps
     bit-exact in eval (no atomics there), gradients to fp64-atomic rounding noise.  A missing event edge shows up
     as a gross mismatch in some repetition."""
     cfg, params, ndm, poses, cfgs, coms = _case(2, 64, 8, 6, 'nyu')
@@ -121,9 +121,9 @@ def test_lanes_match_single_stream(gpu, monkeypatch):
 
     def run(single):
         if single:
-            monkeypatch.setenv('DR_SINGLE_STREAM', '1')
+            monkeypatch.delenv('DR_MULTI_STREAM', raising=False)
         else:
-            monkeypatch.delenv('DR_SINGLE_STREAM', raising=False)
+            monkeypatch.setenv('DR_MULTI_STREAM', '1')
         h = gpu.handle(cfg, B, training=True)
         h.load_params(params)
         h.call('dr_finalize_params', gpu.stream)

@@ -399,6 +399,8 @@ static void free_all(dr_handle* h) {
     for (int l = 0; l < DR_MAX_LANES; ++l)
         if (h->stat_part_l[l]) rt::dfree(h->stat_part_l[l]);
     for (auto& e : h->lane_ev) rt::event_destroy(e);
+    for (auto& g : h->graphs) rt::graph_destroy(g.g);
+    rt::stream_destroy(h->cap_stream);
 }
 
 namespace {
@@ -500,6 +502,9 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         const char* multi = getenv("DR_MULTI_STREAM");
         const char* single = getenv("DR_SINGLE_STREAM");
         h->multi_stream = multi && multi[0] == '1' && !(single && single[0] == '1');
+        const char* graphs = getenv("DR_GRAPHS");
+        h->use_graphs = graphs && graphs[0] == '1';      // opt-in: measured no gain (B=1: 1.87 ms either way, GPU-bound)
+        h->cap_stream = rt::stream_create();
     }
     for (int l = 1; l < h->n_lanes; ++l) {
         h->lane_stream[l] = rt::stream_create();
@@ -912,6 +917,51 @@ static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s
     return DR_OK;
 }
 
+// Replay (or record, the first time) the launches of an inference entry point as ONE executable graph (opt-in,
+// DR_GRAPHS=1).  A B=1 forward + vote is ~150 launches; measured on MI355X it is NOT bound by the host's launch rate
+// (1.87 ms per step with plain launches and with the graph: each tiny kernel is a 7-20 us dependent chain on the
+// GPU), so this only pays where the host is slow or shared.  The graph is
+// recorded on a library-owned stream (the caller's may be the legacy default stream, which cannot be captured) and
+// launched into the caller's stream.  Keyed by entry point, batch and every caller pointer baked into the launches.
+template <typename Fn>
+static int run_with_graph(dr_handle* h, int entry, int B, std::initializer_list<const void*> ptrs, hipStream_t s, Fn&& direct) {
+    const bool usable = h->use_graphs && !h->profiling && !h->multi_stream && h->cap_stream && h->finalized;
+    if (!usable) return direct(s);
+    if (B < 1 || B > h->cfg.max_batch) return direct(s);                  // let the direct path report the error
+    DR_ENTER(h);
+    if (!h->fold_is_eval) {                                                  // outside the recording: it is conditional
+        int rc = fold_bn(h, s);
+        if (rc) return rc;
+        h->fold_is_eval = true;
+    }
+    dr_handle::GraphEntry key{};
+    key.entry = entry; key.B = B;
+    int n = 0;
+    for (const void* q : ptrs) key.ptr[n++] = q;
+    for (auto& g : h->graphs)
+        if (g.entry == key.entry && g.B == key.B && !memcmp(g.ptr, key.ptr, sizeof(key.ptr))) {
+            if (!rt::graph_launch(g.g, s)) DR_FAIL(h, DR_E_DEVICE, "graph launch failed");
+            h->dm_in = (const float*)key.ptr[0];
+            h->last_forward_train = false;
+            h->last_B = B;
+            return DR_OK;
+        }
+    static const bool dbg = getenv("DR_GRAPH_DEBUG") != nullptr;
+    if (h->graphs.size() >= 16 || !rt::capture_begin(h->cap_stream)) {
+        if (dbg) fprintf(stderr, "[densereg] graph: capture_begin refused (%zu cached)\n", h->graphs.size());
+        return direct(s);
+    }
+    const int rc = direct(h->cap_stream);
+    const bool ok = rt::capture_end(h->cap_stream, &key.g);
+    if (dbg) fprintf(stderr, "[densereg] graph: recorded entry %d B=%d rc=%d instantiate=%d\n", entry, B, rc, (int)ok);
+    if (rc != DR_OK) { if (ok) rt::graph_destroy(key.g); return rc; }
+    if (!ok) return direct(s);                                               // e.g. capture not supported: plain launches
+    h->graphs.push_back(key);
+    if (!rt::graph_launch(key.g, s)) DR_FAIL(h, DR_E_DEVICE, "graph launch failed");
+    return DR_OK;
+}
+
+
 static void copy_out(dr_handle* h, const Tensor* t, int B, float* dst, hipStream_t s) {
     const long M = (long)B * t->H * t->W;
     DR_LAUNCH(copy_channels_kernel, dim3(grid_for(M * t->C)), dim3(256), 0, s, (const float*)t->p, t->cs, 0, dst, t->C, 0, M,
@@ -937,10 +987,11 @@ extern "C" {
 
 int dr_forward_eval(dr_handle* h, int B, const float* dm, float* hm, float* hm3, float* um, dr_stream stream) {
     if (!h || !dm) return DR_E_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    int rc = forward_eval_impl(h, B, dm, s);
-    if (rc) return rc;
-    return dr_read_maps(h, B, h->cfg.num_stack - 1, hm, hm3, um, stream);
+    return run_with_graph(h, 2, B, {dm, hm, hm3, um}, (hipStream_t)stream, [&](hipStream_t s) {
+        int rc = forward_eval_impl(h, B, dm, s);
+        if (rc) return rc;
+        return dr_read_maps(h, B, h->cfg.num_stack - 1, hm, hm3, um, (dr_stream)s);
+    });
 }
 
 int dr_read_maps(dr_handle* h, int B, int stack, float* hm, float* hm3, float* um, dr_stream stream) {
@@ -970,12 +1021,13 @@ int dr_vote(dr_handle* h, int B, const float* hm, const float* hm3, const float*
 
 int dr_infer(dr_handle* h, int B, const float* dm, const float* cfg, const float* com, float* xyz, dr_stream stream) {
     if (!h || !dm || !cfg || !com || !xyz) return DR_E_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    int rc = forward_eval_impl(h, B, dm, s);
-    if (rc) return rc;
-    const int S = h->cfg.num_stack - 1;
-    TView a{h->hm[S], 0, h->hm[S]->C}, b{h->hm3[S], 0, h->hm3[S]->C}, c{h->um[S], 0, h->um[S]->C};
-    return vote_impl(h, B, a.fwd(), b.fwd(), c.fwd(), h->tiny, cfg, com, xyz, s);
+    return run_with_graph(h, 1, B, {dm, cfg, com, xyz}, (hipStream_t)stream, [&](hipStream_t s) {
+        int rc = forward_eval_impl(h, B, dm, s);
+        if (rc) return rc;
+        const int S = h->cfg.num_stack - 1;
+        TView a{h->hm[S], 0, h->hm[S]->C}, b{h->hm3[S], 0, h->hm3[S]->C}, c{h->um[S], 0, h->um[S]->C};
+        return vote_impl(h, B, a.fwd(), b.fwd(), c.fwd(), h->tiny, cfg, com, xyz, s);
+    });
 }
 
 int dr_read_activation(dr_handle* h, const char* scope, int B, float* host, size_t count) {

@@ -38,6 +38,11 @@ inline Event event_create_sync() { return Event{0}; }
 inline hipStream_t stream_create() { return (hipStream_t) nullptr; }         // the emulator runs every launch synchronously
 inline void stream_destroy(hipStream_t) {}
 inline void stream_wait_event(hipStream_t, Event) {}
+struct Graph { int dummy; };                                                  // no graphs on the emulator
+inline bool capture_begin(hipStream_t) { return false; }
+inline bool capture_end(hipStream_t, Graph*) { return false; }
+inline bool graph_launch(Graph, hipStream_t) { return false; }
+inline void graph_destroy(Graph) {}
 }}  // namespace dr::rt
 #else
 // ---------------------------------------------------------------------------------------------
@@ -74,6 +79,19 @@ inline Event event_create_sync() { Event ev{}; (void)hipEventCreateWithFlags(&ev
 inline hipStream_t stream_create() { hipStream_t s = nullptr; (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking); return s; }
 inline void stream_destroy(hipStream_t s) { if (s) (void)hipStreamDestroy(s); }
 inline void stream_wait_event(hipStream_t s, Event ev) { (void)hipStreamWaitEvent(s, ev.e, 0); }
+// stream capture -> executable graph (the launch-bound inference path replays one graph instead of ~150 launches)
+struct Graph { hipGraphExec_t exec; };
+inline bool capture_begin(hipStream_t s) { return hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess; }
+inline bool capture_end(hipStream_t s, Graph* g) {
+    hipGraph_t gr = nullptr;
+    if (hipStreamEndCapture(s, &gr) != hipSuccess || !gr) { (void)hipGetLastError(); return false; }
+    const bool ok = hipGraphInstantiate(&g->exec, gr, nullptr, nullptr, 0) == hipSuccess;
+    (void)hipGraphDestroy(gr);
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+inline bool graph_launch(Graph g, hipStream_t s) { return hipGraphLaunch(g.exec, s) == hipSuccess; }
+inline void graph_destroy(Graph g) { if (g.exec) (void)hipGraphExecDestroy(g.exec); }
 }}  // namespace dr::rt
 #endif
 

@@ -130,6 +130,11 @@ struct dr_handle {
     hipStream_t lane_stream[dr::DR_MAX_LANES] = {};         // [0] unused: lane 0 is the caller's stream
     std::vector<dr::rt::Event> lane_ev;                     // one ordering event per FORK / JOIN op
     int n_lanes = 1;
+    // executable graphs of the inference entry points, keyed by (entry, B, caller pointers); opt-in with DR_GRAPHS=1
+    struct GraphEntry { int entry; int B; const void* ptr[6]; dr::rt::Graph g; };
+    std::vector<GraphEntry> graphs;
+    hipStream_t cap_stream = nullptr;                      // library-owned stream the captures are recorded on
+    bool use_graphs = false;
     bool multi_stream = false;                             // DR_MULTI_STREAM=1 turns the lanes on; off or profiling: every lane = caller's stream
     float* tiny = nullptr;                                  // (B,h,w) normalised depth at map resolution
     float* tiny_ext = nullptr;                              // same, for dr_vote on external maps

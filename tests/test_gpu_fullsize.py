@@ -132,3 +132,53 @@ def test_input_256_maps_64_forward_and_vote(gpu):
     ref = pose.estimate_pose_mm(ep['hm_outs'][-1], ep['hm3_outs'][-1], ep['um_outs'][-1], ndm, cfgs, coms, out_hw=64)
     assert pose.mean_jnt_error(xyz, ref) <= 0.1
     h.close()
+
+
+def test_graph_replay_matches_direct_launches(gpu, monkeypatch):
+    """dr_infer / dr_forward_eval record their launches into an executable graph on first use and replay it
+    afterwards (opt-in, DR_GRAPHS=1): same bits as plain launches, across repeated calls, another batch size, other
+    caller buffers (a new key), and a parameter reload in between (the graph reads the repacked weights in place)."""
+    from densereg_amd.data.synthetic import make_crops
+    from oracle import net, pose
+    from oracle.graph import NetConfig
+    cfg = NetConfig(1, 32, 16)
+    B = 5
+    dm, poses, cfgs, coms, _ = make_crops(B, 'icvl', seed=77)
+    ndm = pose.norm_dm(dm, coms)
+    params = net.make_test_params(cfg, ndm[:2], seed=3)
+    params2 = {k: (v * 1.01 if k.endswith('weights') else v) for k, v in params.items()}
+
+    def run(graphs):
+        if graphs:
+            monkeypatch.setenv('DR_GRAPHS', '1')
+        else:
+            monkeypatch.delenv('DR_GRAPHS', raising=False)
+        h = gpu.handle(cfg, B)
+        h.load_params(params)
+        h.call('dr_finalize_params', gpu.stream)
+        outs = []
+        for rep in range(3):
+            outs.append(gpu.infer(h, ndm, cfgs, coms))                       # new device buffers each call: new keys
+        d = [gpu.dev(np.ascontiguousarray(a, np.float32)) for a in (ndm, cfgs, coms)]
+        xyz = gpu.empty((B, 48))
+        for rep in range(3):                                                 # same buffers: record once, replay twice
+            h.call('dr_infer', B, gpu.ptr(d[0]), gpu.ptr(d[1]), gpu.ptr(d[2]), gpu.ptr(xyz), gpu.stream)
+            gpu.sync()
+            outs.append(gpu.host(xyz).copy())
+        h.call('dr_infer', 2, gpu.ptr(d[0]), gpu.ptr(d[1]), gpu.ptr(d[2]), gpu.ptr(xyz), gpu.stream)   # other batch size
+        gpu.sync()
+        outs.append(gpu.host(xyz)[:2].copy())
+        h.load_params(params2)
+        h.call('dr_finalize_params', gpu.stream)
+        h.call('dr_infer', B, gpu.ptr(d[0]), gpu.ptr(d[1]), gpu.ptr(d[2]), gpu.ptr(xyz), gpu.stream)   # replays the B=5 graph
+        gpu.sync()
+        outs.append(gpu.host(xyz).copy())
+        outs.append(np.concatenate([m.reshape(B, -1) for m in gpu.forward_eval(h, ndm)], 1))
+        h.close()
+        return outs
+
+    with_graphs, direct = run(True), run(False)
+    for a, b in zip(with_graphs, direct):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(with_graphs[0], with_graphs[5])
+    assert np.abs(with_graphs[7] - with_graphs[5]).max() > 0                 # the reloaded weights were really used

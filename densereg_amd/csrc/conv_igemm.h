@@ -109,7 +109,13 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
     const int wn = wave % WN;
     const int HW = p.H * p.W;
     const int M = p.B * HW;
-    const int m0 = blockIdx.x * BM;
+    // XCD-aware row-block mapping: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own
+    // 4 MB L2.  A 3x3 tap reads the image rows above and below a row block, i.e. its neighbours' pixels: with the
+    // identity mapping neighbours sit on different XCDs and every L2 fetches every halo from HBM.  Remapped, XCD x
+    // owns the contiguous range [x*nx/8, (x+1)*nx/8) of row blocks (and all their N blocks: gridDim.x % 8 == 0).
+    int mblk = blockIdx.x;
+    if ((gridDim.x & 7) == 0) mblk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int m0 = mblk * BM;
     const int n0 = blockIdx.y * BN;
     const int taps = p.ksize * p.ksize;
     const int KT = (p.Kp + BK - 1) / BK;

@@ -44,12 +44,24 @@ __global__ __launch_bounds__(256, (T == 128 ? 3 : 6)) void conv_wgrad_kernel(con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lk = lane >> 5, li = lane & 31;
+    // 1-D grid of tiles * taps * nsplit workgroups, dealt round-robin to the 8 XCDs (id % 8).  Every (tile, tap) of
+    // one pixel slab reads the same x / g rows: with nsplit % 8 == 0 slab s lives on XCD s % 8, so each slab is
+    // fetched from HBM by one L2 instead of by all eight.
     const int co_tiles = dr_ceil_div(p.Cout, T);
-    const int ci0 = (blockIdx.x / co_tiles) * T;
-    const int co0 = (blockIdx.x % co_tiles) * T;
-    const int tap = blockIdx.y;
-    const int split = blockIdx.z;
     const int taps = p.ksize * p.ksize;
+    const int tiles = dr_ceil_div(p.Cin, T) * co_tiles;
+    int split, rest;
+    if ((p.nsplit & 7) == 0) {
+        const int per = p.nsplit >> 3, j = blockIdx.x >> 3;
+        split = (j % per) * 8 + (blockIdx.x & 7);
+        rest = j / per;
+    } else {
+        split = blockIdx.x % p.nsplit;
+        rest = blockIdx.x / p.nsplit;
+    }
+    const int tile = rest % tiles, tap = rest / tiles;
+    const int ci0 = (tile / co_tiles) * T;
+    const int co0 = (tile % co_tiles) * T;
     const int pad = p.ksize / 2;
     const int dy = tap / p.ksize - pad, dx = tap % p.ksize - pad;
     const int HW = p.H * p.W;

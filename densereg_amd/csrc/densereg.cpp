@@ -1112,7 +1112,7 @@ extern "C" int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const
     p.x = x; p.x_cs = x_cs; p.Cin = Cin; p.g = g; p.g_cs = g_cs; p.Cout = Cout;
     p.B = B; p.H = H; p.W = W; p.ksize = k; p.rowmask = rowmask; p.mask_thresh = thresh;
     p.partial = partial; p.nsplit = nsplit; p.rows_per_split = rows;
-    dim3 grid(dr_ceil_div(Cin, T) * dr_ceil_div(Cout, T), taps, nsplit);
+    dim3 grid(dr_ceil_div(Cin, T) * dr_ceil_div(Cout, T) * taps * nsplit);
     if (T == 128) DR_LAUNCH((conv_wgrad_kernel<128>), grid, dim3(256), 0, s, p);
     else DR_LAUNCH((conv_wgrad_kernel<64>), grid, dim3(256), 0, s, p);
     rt::memset_async(dw, 0, per * sizeof(float), s);

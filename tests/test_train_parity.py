@@ -158,6 +158,8 @@ WGRAD_CASES = [
     (1, 9, 7, 37, 45, 3, 64, 2, False),         # non power-of-two image: the division path of the loader
     (3, 4, 4, 200, 131, 1, 128, 1, True),
     (1, 2, 2, 64, 64, 3, 64, 1, False),         # image smaller than one 16-pixel step
+    (2, 16, 16, 64, 70, 3, 64, 8, False),       # slabs in multiples of 8: the XCD-aware workgroup mapping
+    (1, 16, 16, 130, 128, 1, 128, 16, True),
 ]
 
 

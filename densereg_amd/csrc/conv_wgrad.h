@@ -242,17 +242,33 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* x, int B, 
         const int tap = tg + 8 * i;
         ty[i] = tap / k - pad_t; tx[i] = tap % k - pad_l;
     }
-    int b = m0 / HWo, rem = m0 % HWo;
-    int oy = rem / Wo, ox = rem % Wo;
-    for (int m = m0; m < m1; ++m) {
-        const float gv = g[(long)m * g_cs + n];
-        const float* xb = x + (long)b * H * W;
+    // pixels in groups of 8: the eight gradient rows and then, per tap, the eight input pixels are loaded as
+    // independent batches (one pixel per iteration was a chain of dependent HBM round trips: 333 us for 0.5 GFLOP)
+    constexpr int U = 8;
+    for (int mg = m0; mg < m1; mg += U) {
+        float gv[U];
+        int by[U], bx[U], bo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = mg + u < m1 ? mg + u : m1 - 1;                  // tail: re-read the last pixel, weight 0
+            gv[u] = mg + u < m1 ? g[(long)m * g_cs + n] : 0.f;
+            const int b = m / HWo, rem = m % HWo;
+            by[u] = (rem / Wo) * stride; bx[u] = (rem % Wo) * stride; bo[u] = b * H * W;
+        }
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            const int iy = oy * stride + ty[i], ix = ox * stride + tx[i];
-            if (tg + 8 * i < k * k && iy >= 0 && iy < H && ix >= 0 && ix < W) acc[i] = fmaf(xb[iy * W + ix], gv, acc[i]);
+            if (tg + 8 * i >= k * k) break;
+            float xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int iy = by[u] + ty[i], ix = bx[u] + tx[i];
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                xv[u] = x[ok ? bo[u] + iy * W + ix : 0];
+                if (!ok) xv[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[i] = fmaf(xv[u], gv[u], acc[i]);
         }
-        if (++ox == Wo) { ox = 0; if (++oy == Ho) { oy = 0; ++b; } }
     }
     float* row = partial + (long)blockIdx.x * k * k * 32;
 #pragma unroll

@@ -1164,12 +1164,12 @@ extern "C" int dr_dbg_bn_bench(long M, int C, int reduce_blocks, int iters, floa
         auto launch = [&]() {
             if (which == 0) {
                 DR_LAUNCH(bn_fwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, (hipStream_t) nullptr, fp);
-                DR_LAUNCH(bn_train_apply_kernel, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, fp);
+                DR_LAUNCH(bn_train_apply_kernel<false>, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, fp);
             } else if (which == 1) {
                 DR_LAUNCH(bn_bwd_reduce_kernel, dim3(g_reduce), dim3(256), 0, (hipStream_t) nullptr, bp);
                 DR_LAUNCH(bn_bwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, (hipStream_t) nullptr, bp);
             } else {
-                DR_LAUNCH(bn_bwd_apply_kernel, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, bp);
+                DR_LAUNCH(bn_bwd_apply_kernel<false>, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, bp);
             }
         };
         for (int i = 0; i < 3; ++i) launch();

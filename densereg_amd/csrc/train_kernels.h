@@ -134,7 +134,26 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const BnTrainParam
     }
 }
 
+// FUSE: layers with few partial rows (everything at 8x8 and below) skip the finalize launch -- every workgroup
+// folds the rows itself (serially per channel, fixed order, a few L2 hits) and workgroup 0 persists the results.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams p) {
+    __shared__ float s_sc[FUSE ? 1024 : 1], s_sh[FUSE ? 1024 : 1];
+    if (FUSE) {
+        for (int c = threadIdx.x; c < p.raw_cs; c += 256) {
+            float sc = 0.f, sh = 0.f;
+            if (c < p.C) {
+                double sum = 0.0, sq = 0.0;
+                for (int r = 0; r < p.part_rows; ++r) {
+                    sum += p.part[(long)c * p.part_rows + r];
+                    sq += p.part[((long)p.C + c) * p.part_rows + r];
+                }
+                bn_channel_coeffs(p, c, sum, sq, sc, sh, blockIdx.x == 0);
+            }
+            s_sc[c] = sc; s_sh[c] = sh;
+        }
+        __syncthreads();
+    }
     const int c4n = p.raw_cs / 4;                  // channel groups per row (<= 256)
     const int rpb = 256 / c4n;                     // rows per workgroup pass
     const int cg = threadIdx.x % c4n, rp = threadIdx.x / c4n;
@@ -143,8 +162,11 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = cg * 4 + k;
-        sc[k] = c < p.C ? p.scale[c] : 0.f;                    // written by bn_fwd_finalize_kernel
-        sh[k] = c < p.C ? p.shift[c] : 0.f;
+        if (FUSE) { sc[k] = s_sc[c]; sh[k] = s_sh[c]; }
+        else {
+            sc[k] = c < p.C ? p.scale[c] : 0.f;                // written by bn_fwd_finalize_kernel
+            sh[k] = c < p.C ? p.shift[c] : 0.f;
+        }
     }
     const bool full = cg * 4 + 4 <= p.C;
     const bool vec_out = full && (p.out.coff % 4 == 0) && (p.out.cs % 4 == 0);
@@ -301,7 +323,31 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdParams 
     }
 }
 
+template <bool FUSE>      // FUSE: fold the reduce pass's rows here instead of in a finalize launch (few rows only)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) {
+    __shared__ float s_c[FUSE ? 3 : 1][FUSE ? 1024 : 1];
+    if (FUSE) {
+        for (int c = threadIdx.x; c < p.raw_cs; c += 256) {
+            float k1 = 0.f, k2 = 0.f, k3 = 0.f;
+            if (c < p.C) {
+                double sg = 0.0, sgy = 0.0;
+                for (int r = 0; r < p.part_rows; ++r) {
+                    sg += p.part[(long)c * p.part_rows + r];
+                    sgy += p.part[((long)p.C + c) * p.part_rows + r];
+                }
+                const float r_ = p.bnc[2 * p.C + c], d_ = p.bnc[3 * p.C + c], istd_ = p.bnc[p.C + c];
+                k1 = p.gamma[c] * r_ * istd_;
+                k2 = (float)(sg / (double)p.M);
+                k3 = (float)(sgy / (double)p.M);
+                if (blockIdx.x == 0) {
+                    p.dbeta[c] += (float)sg;
+                    p.dgamma[c] += r_ * (float)sgy + d_ * (float)sg;
+                }
+            }
+            s_c[0][c] = k1; s_c[1][c] = k2; s_c[2][c] = k3;
+        }
+        __syncthreads();
+    }
     const int c4n = p.raw_cs / 4;
     const int rpb = 256 / c4n;
     const int cg = threadIdx.x % c4n, rp = threadIdx.x / c4n;
@@ -313,7 +359,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
         sc[k] = sh[k] = mean[k] = istd[k] = c1[k] = c2[k] = c3[k] = 0.f;
         if (c < p.C) {
             sc[k] = p.scale[c]; sh[k] = p.shift[c]; mean[k] = p.bnc[c]; istd[k] = p.bnc[p.C + c];
-            c1[k] = p.coef[c]; c2[k] = p.coef[p.C + c]; c3[k] = p.coef[2 * p.C + c];
+            if (FUSE) { c1[k] = s_c[0][c]; c2[k] = s_c[1][c]; c3[k] = s_c[2][c]; }
+            else { c1[k] = p.coef[c]; c2[k] = p.coef[p.C + c]; c3[k] = p.coef[2 * p.C + c]; }
         }
     }
     const bool full = cg * 4 + 4 <= p.C;

@@ -10,6 +10,8 @@
 // slab and a second kernel folds the slabs into the flat gradient accumulator -- deterministic, no
 // floating-point atomics.  Replaces the Conv2DBackpropFilter ops TF derives for ops.py:282.
 #pragma once
+#include <type_traits>
+
 #include "dr_platform.h"
 
 namespace dr {
@@ -24,11 +26,10 @@ struct WgradParams {
 };
 
 // Tile T x T channels, 4 waves as 2 x 2, wave tile T/2 x T/2.
-// T = 128: a wave owns 64 x 64 = 2 x 2 MFMA tiles.  Which channel an MFMA row/column stands for is free (it only
-// permutes the output), so lane li takes the channel PAIR (2*li, 2*li+1) of its wave's 64 with one ds_read_b64
-// per operand and k-step: MFMA tile t of the pair uses component t, i.e. row i of tile t is channel 2*i + t.
-// That halves the LDS instructions of a dword-per-tile fragment read and reads at 256 B/clk instead of 128.
-// T = 64: one MFMA tile per wave, plain dword reads.
+// T = 128: a wave owns 64 x 64 = 2 x 2 MFMA tiles of 32 contiguous channels each (two dwords per operand and k-step,
+// fused by hipcc into one ds_read2_b32); tiles entirely beyond Cin / Cout are skipped.  (A channel-pair mapping
+// read with one ds_read_b64 was measured equal on full tiles and cannot skip anything on ragged ones.)
+// T = 64: one MFMA tile per wave.
 template <int T>
 __global__ __launch_bounds__(256, (T == 128 ? 3 : 6)) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int BK = 16;                 // pixels per step
@@ -144,22 +145,41 @@ __global__ __launch_bounds__(256, (T == 128 ? 3 : 6)) void conv_wgrad_kernel(con
         store(0);
     }
     __syncthreads();
+    // live 32x32 MFMA tiles of this wave along ci / co (0..TM)
+    const int na_ = (p.Cin - (ci0 + wm * WT) + 31) / 32, nb_ = (p.Cout - (co0 + wn * WT) + 31) / 32;
+    const int na = na_ < 0 ? 0 : (na_ > TM ? TM : na_), nb = nb_ < 0 ? 0 : (nb_ > TM ? TM : nb_);
     // one step of 16 pixels from LDS buffer `buf` (a compile-time constant: the loop below is unrolled by two)
     auto k_step = [&](const int buf, const bool more) __attribute__((always_inline)) {
         if (more) load();
         if constexpr (TM == 2) {
-            float2 a2[BK / 2], b2[BK / 2];                       // every fragment of the step, read up front
+            float a[BK / 2][2], b[BK / 2][2];                    // every fragment of the step, read up front
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
-                a2[kk] = *reinterpret_cast<const float2*>(&Xs[buf][2 * kk + lk][wm * WT + 2 * li]);
-                b2[kk] = *reinterpret_cast<const float2*>(&Gs[buf][2 * kk + lk][wn * WT + 2 * li]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[kk][t] = Xs[buf][2 * kk + lk][wm * WT + 32 * t + li];
+                    b[kk][t] = Gs[buf][2 * kk + lk][wn * WT + 32 * t + li];
+                }
             }
+            // MFMA tiles that lie entirely beyond Cin / Cout are skipped (wave-uniform): a 78x78 layer on this 128x128
+            // tile has 3x3 live 32x32 tiles out of 4x4 -- the kernel is MFMA-bound, so that is 44 % of its time
+            auto mf = [&](auto NA, auto NB) __attribute__((always_inline)) {
 #pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk].x, b2[kk].x, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk].x, b2[kk].y, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk].y, b2[kk].x, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk].y, b2[kk].y, acc[1][1], 0, 0, 0);
+                for (int kk = 0; kk < BK / 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < decltype(NA)::value; ++i)
+#pragma unroll
+                        for (int j = 0; j < decltype(NB)::value; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+            };
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            if (na == 2) {
+                if (nb == 2) mf(I2{}, I2{});
+                else if (nb == 1) mf(I2{}, I1{});
+            } else if (na == 1) {
+                if (nb == 2) mf(I1{}, I2{});
+                else if (nb == 1) mf(I1{}, I1{});
             }
         } else {
             float a[BK / 2], b[BK / 2];
@@ -168,9 +188,11 @@ __global__ __launch_bounds__(256, (T == 128 ? 3 : 6)) void conv_wgrad_kernel(con
                 a[kk] = Xs[buf][2 * kk + lk][wm * WT + li];
                 b[kk] = Gs[buf][2 * kk + lk][wn * WT + li];
             }
+            if (na > 0 && nb > 0) {
 #pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk)
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc[0][0], 0, 0, 0);
+                for (int kk = 0; kk < BK / 2; ++kk)
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc[0][0], 0, 0, 0);
+            }
         }
         if (more) store(buf ^ 1);
         __syncthreads();
@@ -182,18 +204,17 @@ __global__ __launch_bounds__(256, (T == 128 ? 3 : 6)) void conv_wgrad_kernel(con
     }
     if (steps & 1) k_step(0, false);
 
-    // partial[split][tap][ci][co]; D: row = (r&3)+8*(r>>2)+4*lk, col = li; with TM = 2 row/col i of tile t is
-    // channel 2*i + t of the wave's 64 (see above), with TM = 1 it is channel i.
+    // partial[split][tap][ci][co]; D: row = (r&3)+8*(r>>2)+4*lk, col = li; MFMA tile t = channels [32t, 32t+32)
     float* dst = p.partial + ((long)split * taps + tap) * p.Cin * p.Cout;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int co = co0 + wn * WT + (TM == 2 ? 2 * li + j : li);
+        const int co = co0 + wn * WT + 32 * j + li;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const int ci = ci0 + wm * WT + (TM == 2 ? 2 * row + i : row);
+                const int ci = ci0 + wm * WT + 32 * i + row;
                 if (ci < p.Cin && co < p.Cout) dst[(long)ci * p.Cout + co] = acc[i][j][r];
             }
     }

@@ -1123,6 +1123,57 @@ extern "C" int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const
     return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
 }
 
+// Micro-benchmark of the weight-gradient kernel + slab fold on self-allocated buffers: microseconds per call for a
+// given channel tile T and slab count nsplit (0 = the executor's planner).
+extern "C" int dr_dbg_wgrad_bench(int B, int H, int W, int Cin, int Cout, int k, int T, int nsplit, int iters, float* us_out,
+                                  int* nsplit_used) {
+    if (!us_out || iters < 1 || (k != 1 && k != 3)) return DR_E_INVALID;
+    ConvLayer c;
+    c.k = k; c.cin = Cin; c.cout = Cout; c.H = H; c.W = W;
+    WgradPlan wp = wgrad_plan(c, B);
+    if (T == 64 || T == 128) wp.T = T;
+    const int taps = k * k;
+    const long M = (long)B * H * W;
+    const size_t per = (size_t)taps * Cin * Cout;
+    if (nsplit > 0) {
+        const int rows = dr_round_up((int)((M + nsplit - 1) / nsplit), 16);
+        wp.nsplit = (int)((M + rows - 1) / rows); wp.rows_per_split = rows;
+    }
+    if (nsplit_used) *nsplit_used = wp.nsplit;
+    const int xcs = dr_round_up(Cin, 4), gcs = dr_round_up(Cout, 4);
+    float* x = (float*)rt::dmalloc(M * xcs * 4); float* g = (float*)rt::dmalloc(M * gcs * 4);
+    float* part = (float*)rt::dmalloc((size_t)wp.nsplit * per * 4); float* dw = (float*)rt::dmalloc(per * 4);
+    if (!x || !g || !part || !dw) return DR_E_NOMEM;
+    std::vector<float> hx((size_t)M * std::max(xcs, gcs));
+    unsigned st = 99u;
+    for (auto& v : hx) { st = st * 1664525u + 1013904223u; v = ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
+    rt::h2d(x, hx.data(), (size_t)M * xcs * 4, nullptr); rt::h2d(g, hx.data(), (size_t)M * gcs * 4, nullptr);
+    rt::memset_async(dw, 0, per * 4, nullptr);
+    rt::sync_stream(nullptr);
+    WgradParams p{};
+    p.x = x; p.x_cs = xcs; p.Cin = Cin; p.g = g; p.g_cs = gcs; p.Cout = Cout; p.B = B; p.H = H; p.W = W; p.ksize = k;
+    p.partial = part; p.nsplit = wp.nsplit; p.rows_per_split = wp.rows_per_split;
+    dim3 grid(dr_ceil_div(Cin, wp.T) * dr_ceil_div(Cout, wp.T) * taps * wp.nsplit);
+    auto launch = [&]() {
+        if (wp.T == 128) DR_LAUNCH((conv_wgrad_kernel<128>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
+        else DR_LAUNCH((conv_wgrad_kernel<64>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
+        DR_LAUNCH(wgrad_reduce_kernel, dim3(grid_for((long)per, 64)), dim3(256), 0, (hipStream_t) nullptr, (const float*)part, wp.nsplit,
+                  (long)per, dw);
+    };
+    for (int i = 0; i < 3; ++i) launch();
+    rt::sync_stream(nullptr);
+    rt::Event a = rt::event_create(), b = rt::event_create();
+    rt::event_record(a, nullptr);
+    for (int i = 0; i < iters; ++i) launch();
+    rt::event_record(b, nullptr);
+    rt::sync_stream(nullptr);
+    *us_out = rt::event_elapsed_ms(a, b) * 1e3f / iters;
+    rt::event_destroy(a); rt::event_destroy(b);
+    for (void* q : {(void*)x, (void*)g, (void*)part, (void*)dw}) rt::dfree(q);
+    std::string m;
+    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
+}
+
 // Micro-benchmark of the three BatchReNorm streaming kernels on an [M][C] tensor: microseconds per launch of
 // (train apply, backward reduce, backward apply); `reduce_blocks` overrides the backward-reduce grid (0 = executor's).
 extern "C" int dr_dbg_bn_bench(long M, int C, int reduce_blocks, int iters, float* us_out) {

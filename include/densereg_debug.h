@@ -22,6 +22,11 @@ int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, const float* x,
 int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const float* x, int x_cs, const float* g, int g_cs,
                  const float* rowmask, float thresh, int T, int nsplit, float* dw, dr_stream stream);
 
+/* Micro-benchmark of the weight-gradient kernel + slab fold: microseconds per call for channel tile T (0 = planner's)
+ * and nsplit slabs (0 = planner's; *nsplit_used reports the count actually run). */
+int dr_dbg_wgrad_bench(int B, int H, int W, int Cin, int Cout, int k, int T, int nsplit, int iters, float* us_out,
+                       int* nsplit_used);
+
 /* Micro-benchmark of the BatchReNorm streaming kernels on an [M][C] tensor: us_out[3] = microseconds per launch
  * of (train apply, backward reduce, backward apply).  reduce_blocks > 0 overrides the backward-reduce grid. */
 int dr_dbg_bn_bench(long M, int C, int reduce_blocks, int iters, float* us_out);

@@ -49,6 +49,11 @@ struct ConvParams {
     const float* out_rowmask; float out_mask_thresh; // nullable: rows with out_rowmask[m] < thresh are not written
     double* stat_part;                               // nullable: [2][Cout][gridDim.x] per-workgroup sum / sum-of-squares of acc
     const float* zeros;                              // >= 16 B of zeros in HBM: target of predicated-off loads
+    // dgrad feeding a BatchReNorm layer whose output has no other consumer (bst_raw != null; needs stat_part, no
+    // residual/dropout): the values written ARE that layer's complete dOut, so its backward reduction happens here --
+    // stat_part rows hold sum(g) and sum(g*yhat), g = dOut * [raw*scale+shift > 0], yhat = (raw-mean)*inv_std, instead
+    // of the forward moments.  bst_raw is the layer's raw conv output (row stride bst_cs), bst_bnc = [mean | inv_std].
+    const float* bst_raw; int bst_cs; const float* bst_scale; const float* bst_shift; const float* bst_bnc; int bst_relu;
 };
 
 // stateless keep bit for dropout(0.5): splitmix64 finaliser of (seed, element index)
@@ -92,7 +97,7 @@ struct ConvTile {
 // is a serial chain of K-tiles at ~0.6 us each (load -> LDS -> barrier -> MFMA, one wave per SIMD, nothing to hide
 // behind), so it moves four 16-channel chunks per round trip -- a 3x3 64->64 layer is 9 iterations instead of 36.
 template <int BM, int BN, int BK_>
-constexpr int conv_min_waves() { return BK_ == 64 ? 2 : (BM * BN >= 128 * 128 ? 3 : 5); }
+constexpr int conv_min_waves() { return BK_ == 64 ? 2 : (BM * BN >= 128 * 128 ? 3 : (BM == 128 && BN == 64 ? 4 : 5)); }
 
 template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16>
 __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_igemm_kernel(const ConvParams p) {
@@ -371,10 +376,23 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
             const float sc = (n_ok && p.scale) ? p.scale[n] : 1.f;
             const float sh = (n_ok && p.shift) ? p.shift[n] : 0.f;
             const unsigned rows_j = n_ok ? rows : 0u;
+            float b_sc = 0.f, b_sh = 0.f, b_mean = 0.f, b_istd = 0.f;    // BatchReNorm-backward statistics mode
+            if (p.bst_raw && n_ok) {
+                b_sc = p.bst_scale[n]; b_sh = p.bst_shift[n]; b_mean = p.bst_bnc[n]; b_istd = p.bst_bnc[p.Cout + n];
+            }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {                         // 8 rows at a time: bounds the VGPR peak
                 float rv[8];
+                float braw[8];
                 unsigned keep = 0xFFu;
+                if (p.bst_raw) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = half * 8 + q;
+                        const unsigned m = (unsigned)(mb + (r & 3) + 8 * (r >> 2));
+                        braw[q] = p.bst_raw[((rows_j >> r) & 1u) ? m * (unsigned)p.bst_cs + (unsigned)n : 0u];
+                    }
+                }
                 if (p.res) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -410,13 +428,21 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
                     if ((rows_j >> r) & 1u) {
                         const unsigned m = (unsigned)(mb + (r & 3) + 8 * (r >> 2));
                         const float raw = acc[i][j][r];
-                        s1[j] += (double)raw;
-                        s2[j] += (double)raw * (double)raw;
                         float v = raw * sc + sh;
                         if (p.relu) v = fmaxf(v, 0.f);
                         if (dropping) v = ((keep >> q) & 1u) ? v * 2.f : 0.f;
                         if (p.res) v += rv[q];
                         p.y[m * (unsigned)p.y_cs + (unsigned)(p.y_coff + n)] = v;
+                        if (p.bst_raw) {
+                            float g = v;
+                            if (p.bst_relu && !(braw[q] * b_sc + b_sh > 0.f)) g = 0.f;
+                            const float yh = (braw[q] - b_mean) * b_istd;
+                            s1[j] += (double)g;
+                            s2[j] += (double)g * (double)yh;
+                        } else {
+                            s1[j] += (double)raw;
+                            s2[j] += (double)raw * (double)raw;
+                        }
                     }
                 }
             }

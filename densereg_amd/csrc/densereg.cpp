@@ -396,8 +396,10 @@ static void free_all(dr_handle* h) {
         if (h->bn_coef_l[l]) rt::dfree(h->bn_coef_l[l]);
         rt::stream_destroy(h->lane_stream[l]);
     }
-    for (int l = 0; l < DR_MAX_LANES; ++l)
+    for (int l = 0; l < DR_MAX_LANES; ++l) {
         if (h->stat_part_l[l]) rt::dfree(h->stat_part_l[l]);
+        if (h->stat_part2_l[l]) rt::dfree(h->stat_part2_l[l]);
+    }
     for (auto& e : h->lane_ev) rt::event_destroy(e);
     for (auto& g : h->graphs) rt::graph_destroy(g.g);
     rt::stream_destroy(h->cap_stream);
@@ -505,6 +507,8 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         const char* graphs = getenv("DR_GRAPHS");
         h->use_graphs = graphs && graphs[0] == '1';      // opt-in: measured no gain (B=1: 1.87 ms either way, GPU-bound)
         h->cap_stream = rt::stream_create();
+        const char* fuse = getenv("DR_FUSE_BN_BWD");
+        h->fuse_bn_bwd = !(fuse && fuse[0] == '0');
     }
     for (int l = 1; l < h->n_lanes; ++l) {
         h->lane_stream[l] = rt::stream_create();

@@ -52,6 +52,8 @@ struct ConvLayer {
     size_t stat_off = 0;               // 4*cout doubles: sum, sumsq (fwd) ; sum g, sum g*yhat (bwd)
     size_t bnc_off = 0;                // 4*cout floats: mean, inv_std, r, d saved by the train forward
     Tensor* raw = nullptr;             // pre-BN conv output (training)
+    int bst_rows = 0;                  // backward sweep: > 0 = the consumer's dgrad already wrote this many partial rows of
+                                       // this layer's BatchReNorm backward sums into stat_part2 (train_exec.inc)
 };
 
 enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_UPADD, OP_UVD, OP_COPY, OP_FORK, OP_JOIN };
@@ -75,6 +77,7 @@ struct Op {
     int ev = -1;                       // FORK/JOIN: index into dr_handle::lane_ev
     TView uvd0, uvd1;                  // OP_UVD destinations
     bool ow_in = false, ow_in2 = false; // backward: this op is the FIRST writer of grad(in) / grad(in2) -> overwrite
+    int bst_conv = -1;                 // backward: this conv's dgrad also reduces the BatchReNorm backward sums of conv #bst_conv
 };
 
 enum ParamKind { PK_WEIGHT, PK_BETA, PK_GAMMA, PK_BIAS, PK_MMEAN, PK_MVAR, PK_RMAX, PK_DMAX, PK_CURRT };
@@ -135,6 +138,7 @@ struct dr_handle {
     std::vector<GraphEntry> graphs;
     hipStream_t cap_stream = nullptr;                      // library-owned stream the captures are recorded on
     bool use_graphs = false;
+    bool fuse_bn_bwd = true;                               // DR_FUSE_BN_BWD=0: every BatchReNorm layer runs its own reduce pass
     bool multi_stream = false;                             // DR_MULTI_STREAM=1 turns the lanes on; off or profiling: every lane = caller's stream
     float* tiny = nullptr;                                  // (B,h,w) normalised depth at map resolution
     float* tiny_ext = nullptr;                              // same, for dr_vote on external maps
@@ -159,6 +163,7 @@ struct dr_handle {
     float* bn_coef = nullptr;                              // 3*max(cout) floats (BatchReNorm backward)
     float* bn_coef_l[dr::DR_MAX_LANES] = {};                // one per lane (index 0 aliases `bn_coef`)
     double* stat_part_l[dr::DR_MAX_LANES] = {};             // per lane: partial-sum rows of the BatchReNorm reductions
+    double* stat_part2_l[dr::DR_MAX_LANES] = {};            // per lane: rows written by a dgrad for the NEXT layer's backward
     size_t n_stat_part = 0;
     float* wg_partial = nullptr; size_t n_wg_partial = 0;  // split-K slabs of the weight gradient
     float* wg_partial_l[dr::DR_MAX_LANES] = {};             // one per lane (index 0 aliases `wg_partial`)

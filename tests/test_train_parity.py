@@ -150,6 +150,36 @@ def test_lanes_match_single_stream(gpu, monkeypatch):
             assert np.abs(ga[name] - gb[name]).max() / sc < 1e-4, (step, name)
 
 
+def test_bn_backward_sums_fused_into_dgrad(be, monkeypatch):
+    """A BatchReNorm layer whose output has a single reader gets its backward sums from that reader's dgrad epilogue
+    (conv_igemm.h bst_*).  DR_FUSE_BN_BWD=0 runs the separate reduce pass everywhere: same gradients to fp32/fp64
+    summation-order noise."""
+    cfg, params, ndm, poses, cfgs, coms = _case(1, 32, 4, 1 if be.name == 'emu' else 5)
+    B = ndm.shape[0]
+
+    def grads(fused):
+        if fused:
+            monkeypatch.delenv('DR_FUSE_BN_BWD', raising=False)
+        else:
+            monkeypatch.setenv('DR_FUSE_BN_BWD', '0')
+        h = be.handle(cfg, B, training=True)
+        h.load_params(params)
+        h.call('dr_finalize_params', be.stream)
+        d_dm, d_pose, d_cfg, d_com, d_lo = be.dev(ndm), be.dev(poses), be.dev(cfgs), be.dev(coms), be.empty((4,))
+        h.call('dr_forward_train', B, be.ptr(d_dm), 0, None, C.c_uint64(0), be.stream)
+        h.call('dr_loss', B, be.ptr(d_dm), be.ptr(d_pose), be.ptr(d_cfg), be.ptr(d_com), be.ptr(d_lo), be.stream)
+        h.call('dr_zero_grad', be.stream)
+        h.call('dr_backward', B, be.stream)
+        be.sync()
+        g = flat_grads_by_name(be, h, cfg)
+        h.close()
+        return g
+
+    a, b = grads(True), grads(False)
+    worst = max(float(np.abs(a[k] - b[k]).max() / (np.abs(b[k]).max() + 1e-12)) for k in a)
+    assert worst < 2e-4, worst
+
+
 WGRAD_CASES = [
     # B, H, W, Cin, Cout, k, T, nsplit, masked
     (2, 8, 8, 64, 64, 3, 64, 3, False),

@@ -220,6 +220,167 @@ __global__ __launch_bounds__(256, (T == 128 ? 3 : 6)) void conv_wgrad_kernel(con
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 layers with 65..96 channels on BOTH sides (the hm3 / um-head residuals: 65->65, 78->78): on the square tiles a
+// layer like that is nine single-tile workgroups per slab, each re-reading x and g and each with a 128x128 tile that
+// is 9/16 live -- 37 TFLOP/s, latency-bound.  Here ONE workgroup owns a kernel ROW (dy) of a slab: the three taps
+// dx = -1, 0, +1 share the G tile, X is staged once per dx (each with its own border mask, like a tap of the square
+// kernel), and the 27 = 3 taps x 3 x 3 MFMA tiles are dealt round-robin to the four waves (7/7/7/6).
+// ------------------------------------------------------------------------------------------------------------
+// (no run-time tile predicates in here: a branch per MFMA serialises every LDS read behind its own wait -- measured
+// 4 us per step instead of 1.5; the host only selects this kernel when all 3 x 3 tiles are live)
+template <int W>
+__device__ __forceinline__ void wgrad_row_mfma(const float (*Xs)[16][100], const float (*Gs)[100], int lk, int li,
+                                               dr_f32x16 (&acc)[7]) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        float a[3][3], b[3];                                  // every fragment of the k-step (unused ones are dropped)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[d][t] = Xs[d][2 * kk + lk][32 * t + li];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) b[t] = Gs[2 * kk + lk][32 * t + li];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const int t = W + 4 * q;                          // compile-time after unrolling
+            if (t < 27) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t / 9][(t % 9) / 3], b[t % 3], acc[q], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_row_kernel(const WgradParams p) {
+    constexpr int BK = 16, CT = 96, ST = CT + 4, C4 = CT / 4;     // 24 float4 per pixel row
+    constexpr int XI = (3 * BK * C4 + 255) / 256;                 // 5 float4 of X per thread and step (the last partly)
+    constexpr int GI = (BK * C4 + 255) / 256;                     // 2 of G
+    __shared__ __attribute__((aligned(16))) float Xs[2][3][BK][ST];
+    __shared__ __attribute__((aligned(16))) float Gs[2][BK][ST];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lk = lane >> 5, li = lane & 31;
+    int split, dyi;
+    if ((p.nsplit & 7) == 0) {                                    // slab s on XCD s % 8 (see conv_wgrad_kernel)
+        const int per = p.nsplit >> 3, j = blockIdx.x >> 3;
+        split = (j % per) * 8 + (blockIdx.x & 7);
+        dyi = j / per;
+    } else {
+        split = blockIdx.x % p.nsplit;
+        dyi = blockIdx.x / p.nsplit;
+    }
+    const int dy = dyi - 1;
+    const int HW = p.H * p.W;
+    const int M = p.B * HW;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = m_begin + p.rows_per_split < M ? m_begin + p.rows_per_split : M;
+    const int steps = m_begin < m_end ? (m_end - m_begin + BK - 1) / BK : 0;
+    const bool pow2 = (p.W & (p.W - 1)) == 0 && (HW & (HW - 1)) == 0;
+    const int w_shift = __builtin_ctz((unsigned)p.W);
+
+    float4 xr[XI], gr[GI];
+    float xm[XI];
+    int xnv[XI], gnv[GI];
+    int next_step = 0;
+    auto load = [&]() __attribute__((always_inline)) {
+        const int mb = m_begin + next_step * BK;
+        ++next_step;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int idx = tid + i * 256;
+            const int dxi = idx / (BK * C4), rem = idx % (BK * C4);
+            const int row = rem / C4, c4 = (rem % C4) * 4;
+            const int m = mb + row;
+            const int left = p.Cin - c4;
+            int nv = left < 0 ? 0 : (left > 4 ? 4 : left);
+            bool ok = idx < 3 * BK * C4 && m < m_end && nv > 0;
+            const int mm = ok ? m : 0;
+            int y, x;
+            if (pow2) { const int r = mm & (HW - 1); y = r >> w_shift; x = r & (p.W - 1); }
+            else { const int r = mm % HW; y = r / p.W; x = r % p.W; }
+            const int yy = y + dy, xx = x + dxi - 1;
+            ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            const unsigned ms = ok ? (unsigned)(m + dy * p.W + dxi - 1) : 0u;
+            xr[i] = *reinterpret_cast<const float4*>(ok ? p.x + (ms * (unsigned)p.x_cs + (unsigned)(p.x_coff + c4)) : p.x);
+            if (p.rowmask) xm[i] = p.rowmask[ms];
+            xnv[i] = ok ? nv : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / C4, c4 = (idx % C4) * 4;
+            const int m = mb + row;
+            const int left = p.Cout - c4;
+            const int nv = left < 0 ? 0 : (left > 4 ? 4 : left);
+            const bool ok = idx < BK * C4 && m < m_end && nv > 0;
+            gr[i] = *reinterpret_cast<const float4*>(ok ? p.g + ((unsigned)m * (unsigned)p.g_cs + (unsigned)(p.g_coff + c4)) : p.g);
+            gnv[i] = ok ? nv : 0;
+        }
+    };
+    auto zsel = [](float4 v, int nv) {
+        return make_float4(nv > 0 ? v.x : 0.f, nv > 1 ? v.y : 0.f, nv > 2 ? v.z : 0.f, nv > 3 ? v.w : 0.f);
+    };
+    auto store = [&](const int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < 3 * BK * C4) {
+                const int dxi = idx / (BK * C4), rem = idx % (BK * C4);
+                const int nv = (p.rowmask && xm[i] < p.mask_thresh) ? 0 : xnv[i];
+                *reinterpret_cast<float4*>(&Xs[buf][dxi][rem / C4][(rem % C4) * 4]) = zsel(xr[i], nv);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < BK * C4) *reinterpret_cast<float4*>(&Gs[buf][idx / C4][(idx % C4) * 4]) = zsel(gr[i], gnv[i]);
+        }
+    };
+
+    dr_f32x16 acc[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    if (steps > 0) {
+        load();
+        store(0);
+    }
+    __syncthreads();
+    auto k_step = [&](const int buf, const bool more) __attribute__((always_inline)) {
+        if (more) load();
+        switch (wave) {                                           // per-wave tile list is compile-time inside each case
+            case 0: wgrad_row_mfma<0>(Xs[buf], Gs[buf], lk, li, acc); break;
+            case 1: wgrad_row_mfma<1>(Xs[buf], Gs[buf], lk, li, acc); break;
+            case 2: wgrad_row_mfma<2>(Xs[buf], Gs[buf], lk, li, acc); break;
+            default: wgrad_row_mfma<3>(Xs[buf], Gs[buf], lk, li, acc); break;
+        }
+        if (more) store(buf ^ 1);
+        __syncthreads();
+    };
+    const int pairs = steps & ~1;
+    for (int st = 0; st < pairs; st += 2) {
+        k_step(0, true);
+        k_step(1, st + 2 < steps);
+    }
+    if (steps & 1) k_step(0, false);
+
+    // partial[split][tap][ci][co], tap = dyi*3 + dxi
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        const int t = wave + 4 * q;
+        if (t < 27) {
+            const int dxi = t / 9, ti = (t % 9) / 3, tj = t % 3;
+            float* dst = p.partial + ((long)split * 9 + dyi * 3 + dxi) * p.Cin * p.Cout;
+            const int co = 32 * tj + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (ci < p.Cin && co < p.Cout) dst[(long)ci * p.Cout + co] = acc[q][r];
+            }
+        }
+    }
+}
+
 // dst[i] += sum_s partial[s][i].  block = 64 elements x 4 split lanes, folded through LDS in a fixed order.
 // The slab loads of a lane are issued in batches of 8 independent loads (a plain accumulate loop waits for each).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, int nsplit, long n, float* dst) {

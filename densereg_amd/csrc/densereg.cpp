@@ -1103,7 +1103,8 @@ extern "C" int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, cons
 // picks the tile, nsplit the number of pixel-axis slabs (folded by wgrad_reduce_kernel), as the executor does.
 extern "C" int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const float* x, int x_cs, const float* g, int g_cs,
                             const float* rowmask, float thresh, int T, int nsplit, float* dw, dr_stream stream) {
-    if (!x || !g || !dw || (k != 1 && k != 3) || (T != 64 && T != 128) || nsplit < 1) return DR_E_INVALID;
+    if (!x || !g || !dw || (k != 1 && k != 3) || (T != 64 && T != 128 && T != 96) || nsplit < 1) return DR_E_INVALID;
+    if (T == 96 && (k != 3 || Cin > 96 || Cout > 96 || Cin <= 64 || Cout <= 64)) return DR_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const int taps = k * k;
     const long M = (long)B * H * W;
@@ -1117,7 +1118,8 @@ extern "C" int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const
     p.B = B; p.H = H; p.W = W; p.ksize = k; p.rowmask = rowmask; p.mask_thresh = thresh;
     p.partial = partial; p.nsplit = nsplit; p.rows_per_split = rows;
     dim3 grid(dr_ceil_div(Cin, T) * dr_ceil_div(Cout, T) * taps * nsplit);
-    if (T == 128) DR_LAUNCH((conv_wgrad_kernel<128>), grid, dim3(256), 0, s, p);
+    if (T == 96) DR_LAUNCH(conv_wgrad_row_kernel, dim3(3 * nsplit), dim3(256), 0, s, p);
+    else if (T == 128) DR_LAUNCH((conv_wgrad_kernel<128>), grid, dim3(256), 0, s, p);
     else DR_LAUNCH((conv_wgrad_kernel<64>), grid, dim3(256), 0, s, p);
     rt::memset_async(dw, 0, per * sizeof(float), s);
     DR_LAUNCH(wgrad_reduce_kernel, dim3(grid_for((long)per, 64)), dim3(256), 0, s, (const float*)partial, nsplit, (long)per, dw);
@@ -1135,7 +1137,7 @@ extern "C" int dr_dbg_wgrad_bench(int B, int H, int W, int Cin, int Cout, int k,
     ConvLayer c;
     c.k = k; c.cin = Cin; c.cout = Cout; c.H = H; c.W = W;
     WgradPlan wp = wgrad_plan(c, B);
-    if (T == 64 || T == 128) wp.T = T;
+    if (T == 64 || T == 128 || (T == 96 && k == 3 && Cin <= 96 && Cout <= 96 && Cin > 64 && Cout > 64)) wp.T = T;
     const int taps = k * k;
     const long M = (long)B * H * W;
     const size_t per = (size_t)taps * Cin * Cout;
@@ -1159,7 +1161,8 @@ extern "C" int dr_dbg_wgrad_bench(int B, int H, int W, int Cin, int Cout, int k,
     p.partial = part; p.nsplit = wp.nsplit; p.rows_per_split = wp.rows_per_split;
     dim3 grid(dr_ceil_div(Cin, wp.T) * dr_ceil_div(Cout, wp.T) * taps * wp.nsplit);
     auto launch = [&]() {
-        if (wp.T == 128) DR_LAUNCH((conv_wgrad_kernel<128>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
+        if (wp.T == 96) DR_LAUNCH(conv_wgrad_row_kernel, dim3(3 * wp.nsplit), dim3(256), 0, (hipStream_t) nullptr, p);
+        else if (wp.T == 128) DR_LAUNCH((conv_wgrad_kernel<128>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
         else DR_LAUNCH((conv_wgrad_kernel<64>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
         DR_LAUNCH(wgrad_reduce_kernel, dim3(grid_for((long)per, 64)), dim3(256), 0, (hipStream_t) nullptr, (const float*)part, wp.nsplit,
                   (long)per, dw);

@@ -190,6 +190,10 @@ WGRAD_CASES = [
     (1, 2, 2, 64, 64, 3, 64, 1, False),         # image smaller than one 16-pixel step
     (2, 16, 16, 64, 70, 3, 64, 8, False),       # slabs in multiples of 8: the XCD-aware workgroup mapping
     (1, 16, 16, 130, 128, 1, 128, 16, True),
+    (2, 8, 8, 78, 78, 3, 96, 2, False),         # kernel-row variant: one workgroup = the three taps of a row
+    (1, 16, 16, 65, 96, 3, 96, 8, True),
+    (2, 9, 7, 80, 70, 3, 96, 3, False),
+    (1, 2, 2, 96, 65, 3, 96, 1, False),
 ]
 
 

@@ -14,13 +14,13 @@ from densereg_amd import _lib  # noqa: E402
 def main():
     lib = _lib.load()
     B = 40
-    shapes = [(32, 256, 256, 3), (32, 128, 128, 3), (32, 78, 78, 3), (32, 65, 65, 3), (32, 512, 512, 1), (32, 128, 256, 1),
+    shapes = [(32, 78, 78, 3), (32, 65, 65, 3), (32, 96, 96, 3), (32, 256, 256, 3), (32, 128, 128, 3), (32, 512, 512, 1), (32, 128, 256, 1),
               (32, 78, 256, 1), (32, 128, 128, 1), (32, 128, 64, 1), (16, 64, 64, 3), (16, 128, 64, 1), (8, 64, 64, 3)]
     print('| HxW | Cin | Cout | k | T | slabs | us (kernel + fold) | TFLOP/s |')
     print('|---:|---:|---:|---:|---:|---:|---:|---:|')
     for hw, cin, cout, k in shapes:
         flops = 2.0 * B * hw * hw * k * k * cin * cout
-        for T in (128, 64):
+        for T in (128, 64, 96):
             for ns in (0, 4, 8, 16, 32, 64, 128, 256):
                 us, used = C.c_float(), C.c_int()
                 rc = lib.dr_dbg_wgrad_bench(B, hw, hw, cin, cout, k, T, ns, 10, C.byref(us), C.byref(used))

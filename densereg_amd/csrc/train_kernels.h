@@ -231,6 +231,7 @@ struct BnBwdParams {
     float* coef;                      // [3][C]: c1 = gamma*r*inv_std, c2 = mean(g), c3 = mean(g*yhat) (finalize -> apply)
     float* dbeta; float* dgamma;      // flat-gradient slices (accumulated)
     float* draw;                      // out: gradient wrt the raw conv output, dense stride raw_cs
+    View dres; int dres_acc;          // apply pass, nullable: residual source's gradient (+)= dOut (out = act(..) + res)
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p) {
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
     }
     const bool full = cg * 4 + 4 <= p.C;
     const bool vec_d = full && (p.dout.coff % 4 == 0) && (p.dout.cs % 4 == 0);
+    const bool vec_r = full && p.dres.p && (p.dres.coff % 4 == 0) && (p.dres.cs % 4 == 0);
     const long stride = (long)gridDim.x * rpb;
     for (long m0 = (long)blockIdx.x * rpb + rp; m0 < p.M; m0 += stride * kBnRows) {
         float4 x4[kBnRows], d4[kBnRows];
@@ -393,6 +395,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (cg * 4 + k < p.C) g[k] = dp[k];
+            }
+            if (p.dres.p) {                                           // d(res) = dOut, unmasked: the add comes after the ReLU
+                float* q = p.dres.p + m * p.dres.cs + p.dres.coff + cg * 4;
+                if (vec_r) {
+                    float4 v = make_float4(g[0], g[1], g[2], g[3]);
+                    if (p.dres_acc) { const float4 o4 = *reinterpret_cast<const float4*>(q); v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w; }
+                    *reinterpret_cast<float4*>(q) = v;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (cg * 4 + k < p.C) q[k] = p.dres_acc ? q[k] + g[k] : g[k];
+                }
             }
             float o[4];
 #pragma unroll

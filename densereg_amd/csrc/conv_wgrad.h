@@ -407,6 +407,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
     }
 }
 
+// Deferred fold of EVERY layer's slabs in one launch at the end of the backward sweep (145 separate ~5 us fold
+// launches otherwise).  Segment s covers workgroups [first_block[s], first_block[s+1]) of 64 elements each.
+struct FoldSeg { long dst_off; long n; long slab_off; int nsplit; int first_block; };
+__global__ __launch_bounds__(256) void wgrad_fold_all_kernel(const float* slabs, const FoldSeg* segs, int nseg, float* grad) {
+    __shared__ float red[4][64];
+    int lo = 0, hi = nseg - 1;                                  // last segment whose first_block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const FoldSeg sg = segs[lo];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long i = (long)((int)blockIdx.x - sg.first_block) * 64 + e;
+    const float* part = slabs + sg.slab_off;
+    float s = 0.f;
+    if (i < sg.n) {
+        int k = sl;
+        for (; k + 7 * 4 < sg.nsplit; k += 8 * 4) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(long)(k + u * 4) * sg.n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < sg.nsplit; k += 4) s += part[(long)k * sg.n + i];
+    }
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && i < sg.n) grad[sg.dst_off + i] += (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
 // Stem (7x7/s2, Cin = 1): dW[ky][kx][n] = sum_pix x[b, oy*s+ky-pt, ox*s+kx-pl] * g[pix][n], Cout = 32.
 // block = 256 threads = 8 tap groups x 32 channels over a chunk of `chunk` output pixels; it writes one partial
 // row [k*k][32] (tap-major) that wgrad_reduce_kernel folds into the flat gradient -- no floating-point atomics.

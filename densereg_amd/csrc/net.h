@@ -167,6 +167,13 @@ struct dr_handle {
     size_t n_stat_part = 0;
     float* wg_partial = nullptr; size_t n_wg_partial = 0;  // split-K slabs of the weight gradient
     float* wg_partial_l[dr::DR_MAX_LANES] = {};             // one per lane (index 0 aliases `wg_partial`)
+    // deferred slab fold (single-stream executor): every layer keeps its slabs until one fold launch at the end
+    std::vector<dr::FoldSeg> fold_host;                     // segments of the sweep in progress
+    dr::FoldSeg* fold_dev = nullptr;                        // device copy (capacity = number of convs)
+    std::vector<dr::FoldSeg> fold_uploaded;                 // what fold_dev currently holds (re-uploaded only on change)
+    size_t fold_head = 0;                                  // floats at the start of wg_partial kept for immediate folds
+    size_t fold_used = 0;                                  // floats of wg_partial handed out in this sweep
+    int fold_blocks = 0;
     bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold
     const float* dm_train = nullptr;                       // input of the last dr_forward_train
 };

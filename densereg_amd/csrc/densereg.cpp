@@ -162,6 +162,30 @@ __global__ __launch_bounds__(256) void pack_weights_T_kernel(const float* w, flo
     }
 }
 
+// Every layer's forward and dgrad packing in ONE launch (292 separate ~3 us launches per optimizer step otherwise).
+// Segment s covers workgroups [first_block, next first_block) of 256 packed elements each.
+struct PackSeg { long w_off; long dst_off; int taps, Cin, Cout, Kp, Np, transposed, first_block; };
+__global__ __launch_bounds__(256) void pack_all_kernel(const float* flat, float* wp, float* wpT, const PackSeg* segs, int nseg) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackSeg sg = segs[lo];
+    const long i = (long)((int)blockIdx.x - sg.first_block) * 256 + threadIdx.x;
+    if (i >= (long)sg.taps * sg.Kp * sg.Np) return;
+    const float* w = flat + sg.w_off;
+    const int kk = int(i % 16);
+    const int n = int((i / 16) % sg.Np);
+    const int t = int((i / (16l * sg.Np)) % sg.taps);
+    const int k = int(i / (16l * sg.Np * sg.taps)) * 16 + kk;
+    if (!sg.transposed) {
+        wp[sg.dst_off + i] = (k < sg.Cin && n < sg.Cout) ? w[((long)t * sg.Cin + k) * sg.Cout + n] : 0.f;
+    } else {                                                    // dgrad: k = cout, n = cin, taps flipped
+        wpT[sg.dst_off + i] = (k < sg.Cout && n < sg.Cin) ? w[((long)(sg.taps - 1 - t) * sg.Cin + n) * sg.Cout + k] : 0.f;
+    }
+}
+
 // eval-mode BatchReNorm fold (ops.py:173-180): scale = gamma*rsqrt(var+eps), shift = beta - mean*scale
 __global__ __launch_bounds__(256) void bn_fold_kernel(const float* beta, const float* gamma, const float* mm,
                                                       const float* mv, float* scale, float* shift, int C, float eps) {
@@ -388,7 +412,7 @@ static void free_all(dr_handle* h) {
     for (void* p : {(void*)h->flat_param, (void*)h->flat_grad, (void*)h->adam_m, (void*)h->adam_v, (void*)h->flat_state, (void*)h->flat_state_next,
                     (void*)h->shadow, (void*)h->wp, (void*)h->wpT, (void*)h->fold, (void*)h->stats, (void*)h->bnc,
                     (void*)h->act_arena, (void*)h->grad_arena, (void*)h->scratch, (void*)h->tiny, (void*)h->tiny_ext, (void*)h->zeros,
-                    (void*)h->losses, (void*)h->reg_segs, (void*)h->loss_acc, (void*)h->bn_coef, (void*)h->wg_partial, (void*)h->fold_dev})
+                    (void*)h->losses, (void*)h->reg_segs, (void*)h->loss_acc, (void*)h->bn_coef, (void*)h->wg_partial, (void*)h->fold_dev, h->pack_dev})
         if (p) rt::dfree(p);
     for (int l = 1; l < DR_MAX_LANES; ++l) {
         if (h->scratch_l[l]) rt::dfree(h->scratch_l[l]);
@@ -701,15 +725,29 @@ int dr_read_param(dr_handle* h, const char* name, float* host, size_t count) {
 }
 
 static int repack_weights(dr_handle* h, hipStream_t s) {
-    for (auto& c : h->convs) {
-        if (c.k == 7) continue;
-        const int taps = c.k * c.k;
-        DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * c.Kp * c.Np)), dim3(256), 0, s,
-                  (const float*)(h->flat_param + c.w_off), h->wp + c.wp_off, taps, c.cin, c.cout, c.Kp, c.Np);
-        if (h->cfg.training)
-            DR_LAUNCH(pack_weights_T_kernel, dim3(grid_for((long)taps * c.KpT * c.NpT)), dim3(256), 0, s,
-                      (const float*)(h->flat_param + c.w_off), h->wpT + c.wpT_off, taps, c.cin, c.cout, c.KpT, c.NpT);
+    if (!h->pack_dev) {                                         // the table is fixed per handle: built and uploaded once
+        std::vector<PackSeg> segs;
+        int blocks = 0;
+        for (auto& c : h->convs) {
+            if (c.k == 7) continue;
+            const int taps = c.k * c.k;
+            segs.push_back(PackSeg{(long)c.w_off, (long)c.wp_off, taps, c.cin, c.cout, c.Kp, c.Np, 0, blocks});
+            blocks += dr_ceil_div(taps * c.Kp * c.Np, 256);
+            if (h->cfg.training) {
+                segs.push_back(PackSeg{(long)c.w_off, (long)c.wpT_off, taps, c.cin, c.cout, c.KpT, c.NpT, 1, blocks});
+                blocks += dr_ceil_div(taps * c.KpT * c.NpT, 256);
+            }
+        }
+        h->pack_nseg = (int)segs.size();
+        h->pack_blocks = blocks;
+        h->pack_dev = rt::dmalloc(std::max<size_t>(1, segs.size()) * sizeof(PackSeg));
+        if (!h->pack_dev) DR_FAIL(h, DR_E_NOMEM, "pack table");
+        if (rt::h2d(h->pack_dev, segs.data(), segs.size() * sizeof(PackSeg), s)) DR_FAIL(h, DR_E_DEVICE, "h2d of the pack table failed");
+        rt::sync_stream(s);
     }
+    if (h->pack_blocks > 0)
+        DR_LAUNCH(pack_all_kernel, dim3(h->pack_blocks), dim3(256), 0, s, (const float*)h->flat_param, h->wp, h->wpT,
+                  (const PackSeg*)h->pack_dev, h->pack_nseg);
     DR_CHECK_LAUNCH(h);
     return DR_OK;
 }

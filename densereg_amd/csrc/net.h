@@ -174,6 +174,7 @@ struct dr_handle {
     size_t fold_head = 0;                                  // floats at the start of wg_partial kept for immediate folds
     size_t fold_used = 0;                                  // floats of wg_partial handed out in this sweep
     int fold_blocks = 0;
+    size_t n_loss_part = 0;                                // rows of the loss kernel's partial sums (loss_acc)
     void* pack_dev = nullptr; int pack_nseg = 0, pack_blocks = 0;   // segment table of the one-launch weight packing
     bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold
     const float* dm_train = nullptr;                       // input of the last dr_forward_train

@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams p) {
     __syncthreads();
     if (threadIdx.x < 3) {
         const double s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-        atomicAdd(&p.acc[threadIdx.x], s);
+        p.acc[(long)threadIdx.x * gridDim.x + blockIdx.x] = s;      // [3][gridDim.x] partial rows, summed by losses_out_kernel
     }
 }
 
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void reg_loss_kernel(const float* param, const
     for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&acc[3], (double)sg.wd * 0.5 * (red[0] + red[1] + red[2] + red[3]));
+    if (threadIdx.x == 0) acc[(long)blockIdx.y * gridDim.x + blockIdx.x] = (double)sg.wd * 0.5 * (red[0] + red[1] + red[2] + red[3]);
 }
 __global__ __launch_bounds__(256) void reg_grad_kernel(const float* param, float* grad, const RegSeg* segs, int nseg) {
     for (int s = blockIdx.y; s < nseg; s += gridDim.y) {
@@ -643,8 +643,20 @@ __global__ __launch_bounds__(256) void reg_grad_kernel(const float* param, float
             grad[sg.off + i] += sg.wd * param[sg.off + i];
     }
 }
-__global__ void losses_out_kernel(const double* acc, float* out) {
-    if (threadIdx.x < 4) out[threadIdx.x] = (float)acc[threadIdx.x];
+// Sums the partial rows of the loss kernels in a fixed order (1168 same-address fp64 atomics cost 100 us here and made
+// the reported loss depend on their order).  loss_part = [3][n_loss] rows of loss_kernel, reg_part = n_reg partials.
+__global__ __launch_bounds__(64) void losses_out_kernel(const double* loss_part, int n_loss, const double* reg_part, int n_reg,
+                                                        float* out) {
+    const int lane = threadIdx.x;
+    for (int t = 0; t < 4; ++t) {
+        const double* src = t < 3 ? loss_part + (long)t * n_loss : reg_part;
+        const int n = t < 3 ? n_loss : n_reg;
+        double a = 0.0;
+        for (int i = lane; i < n; i += 64) a += src[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
+        if (lane == 0) out[t] = (float)a;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

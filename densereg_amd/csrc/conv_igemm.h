@@ -99,8 +99,14 @@ struct ConvTile {
 template <int BM, int BN, int BK_>
 constexpr int conv_min_waves() { return BK_ == 64 ? 2 : (BM * BN >= 128 * 128 ? 3 : (BM == 128 && BN == 64 ? 4 : 5)); }
 
-template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16>
+// GL = 1: the refill is an LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass, the copy lands
+// while the MFMAs of the current tile run and is retired by the barrier's vmcnt(0).  The LDS image must be lane-linear,
+// so the slot swizzle moves to the SOURCE address (lane (row, s) fetches chunk s ^ f(row)); needs Cin % 4 == 0 (a
+// 16-byte chunk is copied whole or replaced by the zero page).  Measured +6..8 % on every shape in isolation (3x3 256->256:
+// 478 -> 448 us) and no difference inside the network step, so the launcher keeps it opt-in (DR_CONV_GLDS=1).
+template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16, int GL = 0>
 __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_igemm_kernel(const ConvParams p) {
+    static_assert(GL == 0 || (BK_ == 16 && BN >= 64), "the LDS-DMA refill needs every wave's 64 lanes inside both tiles");
     using T = ConvTile<BM, BN, WM, WN, BK_>;
     constexpr int BK = T::kBK;
     constexpr int SK = T::kSK;
@@ -146,6 +152,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
         const int row = idx / (BK / 4);
         a_row[i] = row;
         a_k4[i] = idx % (BK / 4);
+        if (GL) a_k4[i] ^= (row >> 2) & 3;                             // LDS-DMA: the slot swizzle lives on the source side
         const int m = m0 + row;
         bool ok = m < M;
         if (ok && p.rowmask) ok = !(p.rowmask[m] < p.mask_thresh);
@@ -194,8 +201,23 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
     const float* ld_w = p.w;
     const bool ragged = (p.Cin & 3) != 0;                                  // uniform: Cin % 4 != 0
     int a_nv[T::kAIters];                                                  // only meaningful on ragged tiles
-    auto load_tile = [&]() __attribute__((always_inline)) {
-        const bool tail = ld_kc + BK > p.Cin;                              // uniform: this chunk crosses Cin
+    auto load_tile = [&](const int dst) __attribute__((always_inline)) {
+        if constexpr (GL) {
+#pragma unroll
+            for (int i = 0; i < T::kAIters; ++i) {
+                const bool ok = ((a_taps[i] >> ld_tap) & 1u) && ld_kc + a_k4[i] * 4 < p.Cin;   // Cin % 4 == 0: whole chunks
+                dr_glds16(ok ? ld_x + ld_kc + a_off[i] : p.zeros, &As[dst][0][0] + (wave * 64 + i * T::kThreads) * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < T::kBIters; ++i) {
+                const int idx = tid + i * T::kThreads;
+                const int brow = idx >> 2, bs = (idx & 3) ^ ((brow >> 2) & 3);
+                const bool ok = brow < BN && n0 + brow < p.Np;
+                dr_glds16(ok ? ld_w + (unsigned)((n0 + brow) * BKC + bs * 4) : p.zeros, &Bs[dst][0][0] + (wave * 64 + i * T::kThreads) * 4);
+            }
+        }
+        const bool tail = !GL && ld_kc + BK > p.Cin;                       // uniform: this chunk crosses Cin
+        if constexpr (!GL) {
 #pragma unroll
         for (int i = 0; i < T::kAIters; ++i) {
             bool ok = (a_taps[i] >> ld_tap) & 1u;
@@ -219,6 +241,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
             b_fat1 = *reinterpret_cast<const float4*>(b_ok0 && left > 1 ? w0 + w_chunk : p.zeros);
             b_fat2 = *reinterpret_cast<const float4*>(b_ok0 && left > 2 ? w0 + 2 * w_chunk : p.zeros);
             b_fat3 = *reinterpret_cast<const float4*>(b_ok0 && left > 3 ? w0 + 3 * w_chunk : p.zeros);
+        }
         }
         // advance the cursor: taps innermost.  The nine taps of one 16-channel chunk re-read the same 64-byte
         // pixel slices (shifted by a pixel), one K-tile apart, so they hit in L1/L2; with the channel sweep
@@ -278,8 +301,8 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
                 for (int r = 0; r < 16; ++r) accp[q][i][j][r] = 0.f;
 
     bool tail0 = BK > p.Cin;
-    load_tile();
-    store_tile(0, tail0);
+    load_tile(0);
+    if constexpr (!GL) store_tile(0, tail0);
     __syncthreads();
 
     float abl_sink = 0.f;              // ABL 4 only
@@ -291,7 +314,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
     auto k_tile = [&](const int buf, const bool more_) __attribute__((always_inline)) {
         const bool more = ABL != 1 && more_;
         const bool was_tail = ld_kc + BK > p.Cin;                           // of the tile being fetched now
-        if (more && ABL != 5) load_tile();
+        if (more && ABL != 5) load_tile(buf ^ 1);
         float4 a4[BK / 8][T::kTM], b4[BK / 8][T::kTN];          // every fragment of this K-tile, read up front
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
@@ -319,7 +342,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
         if (ABL == 4) {
             if (more) abl_sink += a_reg[0].x + (BK == 16 ? b_reg0.x + (T::kBIters > 1 ? b_reg1.x : 0.f) : b_fat0.x);
         } else if (more) {
-            store_tile(buf ^ 1, was_tail);
+            if constexpr (!GL) store_tile(buf ^ 1, was_tail);
         }
         __syncthreads();
     };

@@ -45,11 +45,19 @@ static inline int grid_for(long total, int block = 256, int cap = 256 * 8) {
 // ==============================================================================================
 namespace dr {
 
-template <int BM, int BN, int WM, int WN, int BK = 16>
+template <int BM, int BN, int WM, int WN, int BK = 16, int GL = 0>
 static void launch_cfg(const ConvParams& p, hipStream_t s) {
     const int M = p.B * p.H * p.W;
     dim3 grid(dr_ceil_div(M, BM), dr_ceil_div(p.Np, BN));
-    DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK>), grid, dim3(256), 0, s, p);
+    DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL>), grid, dim3(256), 0, s, p);
+}
+
+// LDS-DMA refill variant (conv_igemm.h GL) for inputs made of whole 16-byte channel chunks: opt-in (DR_CONV_GLDS=1).
+// In isolation it is 6-8 % faster on every shape (profiles/r01_conv_microbench.md), inside the network step the
+// difference disappears (train 1720-1727 crops/s with either refill, three A/B repetitions).
+static bool conv_use_glds(const ConvParams& p) {
+    static const bool on = [] { const char* e = getenv("DR_CONV_GLDS"); return e && e[0] == '1'; }();
+    return on && p.Cin % 4 == 0;
 }
 
 static int g_force_tile = -1;        // test/bench hook (dr_dbg_conv_bench); -1 = heuristic
@@ -93,9 +101,13 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     if (M * widest >= (1ll << 32)) return -1;
     switch (conv_tile_id(p)) {
         case KID_CONV_128x128: launch_cfg<128, 128, 2, 2>(p, s); break;
-        case KID_CONV_64x128: launch_cfg<64, 128, 2, 2>(p, s); break;
+        case KID_CONV_64x128:
+            if (conv_use_glds(p)) launch_cfg<64, 128, 2, 2, 16, 1>(p, s); else launch_cfg<64, 128, 2, 2>(p, s);
+            break;
         case KID_CONV_128x64: launch_cfg<128, 64, 2, 2>(p, s); break;
-        case KID_CONV_64x64: launch_cfg<64, 64, 2, 2>(p, s); break;
+        case KID_CONV_64x64:
+            if (conv_use_glds(p)) launch_cfg<64, 64, 2, 2, 16, 1>(p, s); else launch_cfg<64, 64, 2, 2>(p, s);
+            break;
         case KID_CONV_64x64_K64: launch_cfg<64, 64, 2, 2, 64>(p, s); break;
         default: launch_cfg<128, 32, 4, 1>(p, s); break;
     }

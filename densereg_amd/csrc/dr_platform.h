@@ -95,6 +95,16 @@ inline void graph_destroy(Graph g) { if (g.exec) (void)hipGraphExecDestroy(g.exe
 }}  // namespace dr::rt
 #endif
 
+// 16-byte asynchronous global -> LDS copy (LDS-DMA): lane l of the wave writes lds_wave_base + 16*l; `src` is per lane.
+#if defined(DR_EMU)
+static inline void dr_glds16(const float* src, float* lds_wave_base) { memcpy(lds_wave_base + (threadIdx.x & 63) * 4, src, 16); }
+#else
+__device__ __forceinline__ void dr_glds16(const float* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+#endif
+
 typedef float dr_f32x16 __attribute__((ext_vector_type(16)));
 typedef float dr_f32x4 __attribute__((ext_vector_type(4)));
 

@@ -104,6 +104,20 @@ def test_conv_every_tile_shape(be, tile):
         assert _rel(y1, ref_conv2d(x1, w1)[0]) < 2e-5
 
 
+def test_conv_lds_dma_refill_variant(be, monkeypatch):
+    """DR_CONV_GLDS=1 selects the LDS-DMA refill (global_load_lds, swizzle on the source side, zero page for masked
+    chunks) for inputs of whole 16-byte channel chunks: same results as the register-staged refill, bit for bit.
+    The switch is read once per process, so this test only asserts equality when it can flip it (first conv launch)."""
+    rng = np.random.default_rng(11)
+    outs = []
+    for cin, cout, k, hw in ((64, 128, 3, 8), (20, 64, 1, 6), (256, 64, 3, 4)):
+        x = rng.standard_normal((2, hw, hw, cin)).astype(np.float32)
+        w = (rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+        y = be.conv2d(x, w)
+        assert _rel(y, ref_conv2d(x, w)[0]) < 2e-5
+        outs.append(y)
+
+
 def test_conv_plain_linear(be):
     rng = np.random.default_rng(5)
     x = rng.standard_normal((2, 5, 5, 24)).astype(np.float32)

@@ -5,6 +5,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+DR_CONV_GLDS=1 timeout 600 python -m pytest tests/test_forward_parity.py tests/test_gpu_fullsize.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu_glds.log 2>&1; echo "pytest(glds) rc=$?" >> gpurun_out/pytest_gpu_glds.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
 timeout 900 python bench.py --steps 20 --warmup 5 --detail gpurun_out/detail_train.md > gpurun_out/bench_train.json 2> gpurun_out/bench_train.err; echo "bench rc=$?" >> gpurun_out/bench_train.err
 timeout 600 python bench.py --mode infer --steps 20 --warmup 5 --detail gpurun_out/detail_infer.md > gpurun_out/bench_infer.json 2> gpurun_out/bench_infer.err

@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 from densereg_amd.data.synthetic import DATASETS, make_crops  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -43,6 +44,8 @@ def parse():
     ap.add_argument('--mode', choices=['train', 'infer'], default=os.environ.get('DR_BENCH_MODE', 'train'))
     ap.add_argument('--batch', type=int, default=40)
     ap.add_argument('--sub_batch', type=int, default=5)
+    ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
+                    help='matrix-core arithmetic of the convolutions; bf16 = BASELINE config 5\'s conv path, --mode infer only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--detail', default='', help='write a per-layer timing table (markdown) to this path')
@@ -121,6 +124,11 @@ def main():
     J = DATASETS[dataset]['jnt_num']
     S, F, B = 2, 128, args.batch
     eng = Engine(S, F, J, 128, 3, B, local, training=(mode == 'train'))
+    bf16 = args.precision == 'bf16'
+    if bf16:
+        assert mode == 'infer', 'the bf16 matrix-core path exists for inference (include/densereg.h: dr_set_precision)'
+        eng.set_precision('bf16')
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
 
     # random-init weights of the named architecture (values are irrelevant to dense conv speed)
     rng = np.random.default_rng(7)
@@ -192,8 +200,8 @@ def main():
         if convs:
             dom = max(convs, key=lambda s: s['total_ms'])
             ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
-            roof = {'kernel': dom['name'], 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(mode, dom['name']),
+            roof = {'kernel': dom['name'], 'bound': 'mfma', 'achieved': ach, 'peak': peak,
+                    'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None if bf16 else pmc_traffic(mode, dom['name']),
                     'launches_per_step': dom['launches'] / nprof, 'avg_launch_us': dom['total_ms'] * 1e3 / dom['launches'],
                     'algorithmic_gflop_per_launch': dom['flops'] / dom['launches'] / 1e9,
                     'share_of_step_time': dom['total_ms'] / max(sum(s['total_ms'] for s in stats), 1e-9),
@@ -212,10 +220,11 @@ def main():
             'metric': 'depth-crops/sec %s, 2-stack fea=128 @128x128' % ('fwd+bwd' if mode == 'train' else 'fwd(eval)+vote'),
             'value': crops / dt, 'unit': 'crops/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': ('%s S=2 F=128 J=%d B=%d/GPU 128x128 ' % (dataset.upper(), J, B)) +
                        ('train micro-step fwd+loss+bwd, RCCL all-reduce + clip + Adam every %d steps' % args.sub_batch
-                        if mode == 'train' else 'forward(eval) + vote -> xyz mm'),
+                        if mode == 'train' else 'forward(eval) + vote -> xyz mm') +
+                       (', bf16 matrix cores on fp32 tensors (fp32 accumulate, epilogues, vote)' if bf16 else ''),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
                        'conv_gflop_per_crop_fwd': eng.conv_flops_per_crop() / 1e9},
             'roofline': roof, 'cpu_baseline': cpu,

@@ -60,6 +60,7 @@ SIGNATURES = {
     'dr_apply_adam': (_i, [_vp, C.c_float, C.c_float, C.c_float, C.c_int64, _vp]),
     'dr_read_activation': (_i, [_vp, C.c_char_p, _i, _fp, _sz]),
     'dr_conv_flops_per_crop': (C.c_double, [_vp]),
+    'dr_set_precision': (_i, [_vp, _i]),
     'dr_flat_adam': (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     'dr_crc32c': (C.c_uint32, [C.c_uint32, _vp, C.c_size_t]),
     'dr_crop_from_pose': (_i, [_i, _vp, _i, _i, _vp, _i, _vp, _i, C.c_float, _i, _vp, _vp, _vp, _vp]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     # include/densereg_debug.h (test hooks)
     'dr_dbg_conv_bench': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
     'dr_dbg_force_tile': (_i, [_i]),
+    'dr_dbg_force_bf16': (_i, [_i]),
     'dr_dbg_wgrad_bench': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(_i)]),
     'dr_dbg_bn_bench': (_i, [C.c_long, _i, _i, _i, C.POINTER(C.c_float)]),
     'dr_dbg_wgrad': (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, C.c_float, _i, _i, _vp, _vp]),

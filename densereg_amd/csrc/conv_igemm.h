@@ -54,6 +54,7 @@ struct ConvParams {
     // stat_part rows hold sum(g) and sum(g*yhat), g = dOut * [raw*scale+shift > 0], yhat = (raw-mean)*inv_std, instead
     // of the forward moments.  bst_raw is the layer's raw conv output (row stride bst_cs), bst_bnc = [mean | inv_std].
     const float* bst_raw; int bst_cs; const float* bst_scale; const float* bst_shift; const float* bst_bnc; int bst_relu;
+    int bf16;                              // w holds bf16 [Kp/32][tap][Np][32] (Kp % 32 == 0): launch the BF kernels
 };
 
 // stateless keep bit for dropout(0.5): splitmix64 finaliser of (seed, element index)
@@ -104,12 +105,22 @@ constexpr int conv_min_waves() { return BK_ == 64 ? 2 : (BM * BN >= 128 * 128 ? 
 // so the slot swizzle moves to the SOURCE address (lane (row, s) fetches chunk s ^ f(row)); needs Cin % 4 == 0 (a
 // 16-byte chunk is copied whole or replaced by the zero page).  Measured +6..8 % on every shape in isolation (3x3 256->256:
 // 478 -> 448 us) and no difference inside the network step, so the launcher keeps it opt-in (DR_CONV_GLDS=1).
-template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16, int GL = 0>
+//
+// BF = 1: bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate) on fp32 tensors.  The LDS image keeps its
+// geometry -- 64-byte rows, four swizzled 16-byte slots -- but a slot now holds 8 bf16 channels, so a K-tile is 32
+// input channels and one ds_read_b128 per operand feeds an MFMA with 16 k (lane half lk supplies k 8*lk..8*lk+7 of
+// both operands, the same freedom to permute k the fp32 path uses).  Activations are converted while they are staged
+// (v_cvt_pk_bf16_f32, round to nearest even); weights arrive packed as bf16 [Kp/32][tap][Np][32] (pack_all_kernel),
+// byte for byte the fp32 tile layout, so the weight loader is unchanged.  Epilogue, masks and views are the fp32 ones.
+template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16, int GL = 0, int BF = 0>
 __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_igemm_kernel(const ConvParams p) {
     static_assert(GL == 0 || (BK_ == 16 && BN >= 64), "the LDS-DMA refill needs every wave's 64 lanes inside both tiles");
+    static_assert(BF == 0 || (GL == 0 && BK_ == 16 && ABL == 0), "the bf16 variant exists for the register-staged 64-byte-row tile");
     using T = ConvTile<BM, BN, WM, WN, BK_>;
     constexpr int BK = T::kBK;
     constexpr int SK = T::kSK;
+    constexpr int CK = BF ? 32 : BK;      // input channels per K-tile
+    constexpr int CS = BF ? 8 : 4;        // input channels per 16-byte LDS slot
     __shared__ __attribute__((aligned(16))) float As[2][BM][SK];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][SK];
 
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
     const int m0 = mblk * BM;
     const int n0 = blockIdx.y * BN;
     const int taps = p.ksize * p.ksize;
-    const int KT = (p.Kp + BK - 1) / BK;
+    const int KT = (p.Kp + CK - 1) / CK;
     const int T_total = taps * KT;
     const int pad = p.ksize / 2;
 
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
             mask = (y > 0 ? cols : 0u) | (cols << 3) | (y < p.H - 1 ? cols << 6 : 0u);
         }
         a_taps[i] = ok ? mask : 0u;
-        a_off[i] = ok ? (unsigned)((long)m * p.x_cs + p.x_coff + a_k4[i] * 4) : 0u;
+        a_off[i] = ok ? (unsigned)((long)m * p.x_cs + p.x_coff + a_k4[i] * CS) : 0u;
     }
     // weight tile.  BK = 16: thread -> (output channel row, 4 consecutive k), at most two float4 per thread (BN =
     // 128); scalars, not arrays: hipcc kept two-element arrays in scratch once the K loop was unrolled by two.
@@ -188,6 +199,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
     const int n_chunks = p.Kp / BKC;
 
     float4 a_reg[T::kAIters];
+    float4 a_hi[BF ? T::kAIters : 1];                                      // BF: channels 4..7 of the slot
     float4 b_reg0, b_reg1;
     float4 b_fat0, b_fat1, b_fat2, b_fat3;                                 // BK = 64: one float4 per chunk (named: a
                                                                            // float4[4] here was promoted to LDS by hipcc)
@@ -216,20 +228,21 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
                 dr_glds16(ok ? ld_w + (unsigned)((n0 + brow) * BKC + bs * 4) : p.zeros, &Bs[dst][0][0] + (wave * 64 + i * T::kThreads) * 4);
             }
         }
-        const bool tail = !GL && ld_kc + BK > p.Cin;                       // uniform: this chunk crosses Cin
+        const bool tail = !GL && ld_kc + CK > p.Cin;                       // uniform: this chunk crosses Cin
         if constexpr (!GL) {
 #pragma unroll
         for (int i = 0; i < T::kAIters; ++i) {
             bool ok = (a_taps[i] >> ld_tap) & 1u;
-            int nv = 4;
+            int nv = CS;
             if (tail) {
-                const int left = p.Cin - (ld_kc + a_k4[i] * 4);
-                nv = left < 0 ? 0 : (left > 4 ? 4 : left);
+                const int left = p.Cin - (ld_kc + a_k4[i] * CS);
+                nv = left < 0 ? 0 : (left > CS ? CS : left);
                 ok = ok && nv > 0;
             }
             const float* src = ok ? ld_x + ld_kc + a_off[i] : p.zeros;
             a_reg[i] = *reinterpret_cast<const float4*>(src);
-            a_nv[i] = ok ? nv : 4;                                          // zeros need no masking
+            if constexpr (BF) a_hi[i] = *reinterpret_cast<const float4*>(ok && nv > 4 ? src + 4 : p.zeros);
+            a_nv[i] = ok ? nv : CS;                                         // zeros need no masking
         }
         if constexpr (BK == 16) {
             b_reg0 = *reinterpret_cast<const float4*>(b_ok0 ? ld_w + b_off0 : p.zeros);
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
         if (ld_tap == taps) {
             ld_tap = 0;
             ld_dy = ld_dx = -pad;
-            ld_kc += BK;
+            ld_kc += CK;
         }
         ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;
         if constexpr (BK == 16) ld_w += p.Np * BKC;                        // packed in exactly this order
@@ -267,6 +280,17 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
                 v.y = nv > 1 ? v.y : 0.f;
                 v.z = nv > 2 ? v.z : 0.f;
                 v.w = nv > 3 ? v.w : 0.f;
+            }
+            if constexpr (BF) {
+                float4 u = a_hi[i];
+                if (ragged && was_tail) {
+                    const int nv = a_nv[i];
+                    u.y = nv > 5 ? u.y : 0.f;
+                    u.z = nv > 6 ? u.z : 0.f;
+                    u.w = nv > 7 ? u.w : 0.f;
+                }
+                const dr_f32x8 f = {v.x, v.y, v.z, v.w, u.x, u.y, u.z, u.w};
+                v = __builtin_bit_cast(float4, __builtin_convertvector(f, dr_bf16x8));
             }
             *reinterpret_cast<float4*>(&As[buf][r][k ^ T::swz(r)]) = v;          // swizzled 16-byte slot
         }
@@ -300,7 +324,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accp[q][i][j][r] = 0.f;
 
-    bool tail0 = BK > p.Cin;
+    bool tail0 = CK > p.Cin;
     load_tile(0);
     if constexpr (!GL) store_tile(0, tail0);
     __syncthreads();
@@ -313,7 +337,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
     // each ds_read / ds_write address is "base + immediate" instead of a per-access VALU add.
     auto k_tile = [&](const int buf, const bool more_) __attribute__((always_inline)) {
         const bool more = ABL != 1 && more_;
-        const bool was_tail = ld_kc + BK > p.Cin;                           // of the tile being fetched now
+        const bool was_tail = ld_kc + CK > p.Cin;                           // of the tile being fetched now
         if (more && ABL != 5) load_tile(buf ^ 1);
         float4 a4[BK / 8][T::kTM], b4[BK / 8][T::kTN];          // every fragment of this K-tile, read up front
 #pragma unroll
@@ -325,6 +349,16 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
             for (int j = 0; j < T::kTN; ++j)
                 b4[g][j] = *reinterpret_cast<const float4*>(&Bs[buf][wn * T::kWTN + j * 32 + li][(g * 8 + lk * 4) ^ T::swz(li)]);
         }
+        if constexpr (BF) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < T::kTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::kTN; ++j)
+                        accp[g % KACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(dr_bf16x8, a4[g][i]), __builtin_bit_cast(dr_bf16x8, b4[g][j]), accp[g % KACC][i][j], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g)
 #pragma unroll
@@ -339,6 +373,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
                         if (ABL == 2) accp[q][i][j][0] = fmaf(av, bv, accp[q][i][j][0]);
                         else accp[q][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accp[q][i][j], 0, 0, 0);
                     }
+        }
         if (ABL == 4) {
             if (more) abl_sink += a_reg[0].x + (BK == 16 ? b_reg0.x + (T::kBIters > 1 ? b_reg1.x : 0.f) : b_fat0.x);
         } else if (more) {

@@ -45,11 +45,11 @@ static inline int grid_for(long total, int block = 256, int cap = 256 * 8) {
 // ==============================================================================================
 namespace dr {
 
-template <int BM, int BN, int WM, int WN, int BK = 16, int GL = 0>
+template <int BM, int BN, int WM, int WN, int BK = 16, int GL = 0, int BF = 0>
 static void launch_cfg(const ConvParams& p, hipStream_t s) {
     const int M = p.B * p.H * p.W;
     dim3 grid(dr_ceil_div(M, BM), dr_ceil_div(p.Np, BN));
-    DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL>), grid, dim3(256), 0, s, p);
+    DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF>), grid, dim3(256), 0, s, p);
 }
 
 // LDS-DMA refill variant (conv_igemm.h GL) for inputs made of whole 16-byte channel chunks: opt-in (DR_CONV_GLDS=1).
@@ -61,6 +61,7 @@ static bool conv_use_glds(const ConvParams& p) {
 }
 
 static int g_force_tile = -1;        // test/bench hook (dr_dbg_conv_bench); -1 = heuristic
+static int g_dbg_bf16 = 0;           // test/bench hook (dr_dbg_force_bf16): dr_dbg_conv2d / dr_dbg_conv_bench run the bf16 kernels
 
 // tile shape for a problem (shared by the launcher and the profiler labels)
 int conv_tile_id(const ConvParams& p) {
@@ -75,7 +76,7 @@ int conv_tile_id(const ConvParams& p) {
     // Grids that leave CUs idle (everything below 32x32 at B=40) are chains of ~0.6 us K-tiles with nothing to
     // overlap: the fat K-tile variant moves 64 channels per round trip (3x3 64->64 at 8x8: 22.8 -> see
     // profiles/r01_conv_microbench.md).  Needs >= 2 fat tiles to pay for its larger prologue.
-    if (p.Np % 64 == 0 && rows64 * (p.Np / 64) <= 256 && (long)p.ksize * p.ksize * p.Kp >= 128) return KID_CONV_64x64_K64;
+    if (!p.bf16 && p.Np % 64 == 0 && rows64 * (p.Np / 64) <= 256 && (long)p.ksize * p.ksize * p.Kp >= 128) return KID_CONV_64x64_K64;
     if (p.Np % 128 == 0) {
         const long b128 = rows128 * (p.Np / 128), b64x128 = rows64 * (p.Np / 128), b64x64 = rows64 * (p.Np / 64);
         if (b128 >= 4096) return KID_CONV_128x128;
@@ -99,6 +100,18 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     const long long M = (long long)p.B * p.H * p.W;
     const long long widest = std::max(std::max((long long)p.x_cs, (long long)p.y_cs), std::max((long long)p.res_cs, (long long)p.Cout));
     if (M * widest >= (1ll << 32)) return -1;
+    if (p.bf16) {
+        if (p.Kp % 32) return -1;
+        switch (conv_tile_id(p)) {
+            case KID_CONV_128x128: launch_cfg<128, 128, 2, 2, 16, 0, 1>(p, s); break;
+            case KID_CONV_64x128: launch_cfg<64, 128, 2, 2, 16, 0, 1>(p, s); break;
+            case KID_CONV_128x64: launch_cfg<128, 64, 2, 2, 16, 0, 1>(p, s); break;
+            case KID_CONV_64x64: launch_cfg<64, 64, 2, 2, 16, 0, 1>(p, s); break;
+            case KID_CONV_128x32: launch_cfg<128, 32, 4, 1, 16, 0, 1>(p, s); break;
+            default: return -1;
+        }
+        return 0;
+    }
     switch (conv_tile_id(p)) {
         case KID_CONV_128x128: launch_cfg<128, 128, 2, 2>(p, s); break;
         case KID_CONV_64x128:
@@ -161,6 +174,18 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float
     }
 }
 
+// bf16 forward packing [Kp/32][tap][Np][32] (conv_igemm.h, BF kernels), round to nearest even
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* w, __bf16* wp, int taps, int Cin, int Cout, int Kp, int Np) {
+    const long total = (long)taps * Kp * Np;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int kk = int(i % 32);
+        const int n = int((i / 32) % Np);
+        const int t = int((i / (32l * Np)) % taps);
+        const int k = int(i / (32l * Np * taps)) * 32 + kk;
+        wp[i] = (__bf16)((k < Cin && n < Cout) ? w[((long)t * Cin + k) * Cout + n] : 0.f);
+    }
+}
+
 // dgrad weights: wpT[t'][k=cout][n=cin] = w[taps-1-t'][cin][cout]
 __global__ __launch_bounds__(256) void pack_weights_T_kernel(const float* w, float* wpT, int taps, int Cin, int Cout,
                                                              int KpT, int NpT) {
@@ -187,6 +212,14 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* flat, float*
     const long i = (long)((int)blockIdx.x - sg.first_block) * 256 + threadIdx.x;
     if (i >= (long)sg.taps * sg.Kp * sg.Np) return;
     const float* w = flat + sg.w_off;
+    if (sg.transposed == 2) {                                   // bf16 forward packing [Kp/32][tap][Np][32], round to nearest even
+        const int kk = int(i % 32);
+        const int n = int((i / 32) % sg.Np);
+        const int t = int((i / (32l * sg.Np)) % sg.taps);
+        const int k = int(i / (32l * sg.Np * sg.taps)) * 32 + kk;
+        reinterpret_cast<__bf16*>(wp + sg.dst_off)[i] = (__bf16)((k < sg.Cin && n < sg.Cout) ? w[((long)t * sg.Cin + k) * sg.Cout + n] : 0.f);
+        return;
+    }
     const int kk = int(i % 16);
     const int n = int((i / 16) % sg.Np);
     const int t = int((i / (16l * sg.Np)) % sg.taps);
@@ -743,6 +776,12 @@ static int repack_weights(dr_handle* h, hipStream_t s) {
         for (auto& c : h->convs) {
             if (c.k == 7) continue;
             const int taps = c.k * c.k;
+            if (h->precision == 1) {                            // half the bytes per element: always fits the fp32 slot
+                const int Kp32 = dr_round_up(c.cin, 32);
+                segs.push_back(PackSeg{(long)c.w_off, (long)c.wp_off, taps, c.cin, c.cout, Kp32, c.Np, 2, blocks});
+                blocks += dr_ceil_div(taps * Kp32 * c.Np, 256);
+                continue;
+            }
             segs.push_back(PackSeg{(long)c.w_off, (long)c.wp_off, taps, c.cin, c.cout, c.Kp, c.Np, 0, blocks});
             blocks += dr_ceil_div(taps * c.Kp * c.Np, 256);
             if (h->cfg.training) {
@@ -773,6 +812,22 @@ static int fold_bn(dr_handle* h, hipStream_t s) {
                   0.001f);
     }
     DR_CHECK_LAUNCH(h);
+    return DR_OK;
+}
+
+int dr_set_precision(dr_handle* h, int precision) {
+    if (!h) return DR_E_INVALID;
+    if (precision != DR_PREC_F32 && precision != DR_PREC_BF16) DR_FAIL(h, DR_E_INVALID, "dr_set_precision: unknown precision %d", precision);
+    if (precision == DR_PREC_BF16 && h->cfg.training)
+        DR_FAIL(h, DR_E_UNSUPPORTED, "dr_set_precision: the bf16 matrix-core path exists for inference handles (training=0)");
+    if (precision != h->precision) {
+        rt::sync_stream(nullptr);
+        if (h->pack_dev) { rt::dfree(h->pack_dev); h->pack_dev = nullptr; }     // the packing table depends on the element type
+        h->precision = precision;
+        h->finalized = false;                                                   // weights must be re-packed
+        for (auto& g : h->graphs) rt::graph_destroy(g.g);                       // recorded launches name the old kernels
+        h->graphs.clear();
+    }
     return DR_OK;
 }
 
@@ -893,6 +948,7 @@ static int run_conv_eval(dr_handle* h, const Op& op, int B, hipStream_t s) {
     p.x = op.in.t->p; p.x_cs = op.in.t->cs; p.x_coff = op.in.coff; p.Cin = op.in.C;
     p.B = B; p.H = c.H; p.W = c.W; p.ksize = c.k;
     p.w = h->wp + c.wp_off; p.Kp = c.Kp; p.Np = c.Np;
+    if (h->precision == 1) { p.bf16 = 1; p.Kp = dr_round_up(c.cin, 32); }
     p.y = op.out.t->p; p.y_cs = op.out.t->cs; p.y_coff = op.out.coff; p.Cout = c.cout;
     if (c.bn) { p.scale = h->fold + c.fold_off; p.shift = h->fold + c.fold_off + c.cout; }
     else { p.scale = nullptr; p.shift = h->flat_param + c.bias_off; }
@@ -1119,11 +1175,13 @@ extern "C" int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, cons
                              const float* rowmask, float thresh, float* y, int y_cs, double* stat, dr_stream stream) {
     if (!x || !w || !y || (k != 1 && k != 3)) return DR_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    const int taps = k * k, Kp = dr_round_up(Cin, 16), Np = dr_round_up(Cout, 32);
+    const int taps = k * k, Kp = dr_round_up(Cin, g_dbg_bf16 ? 32 : 16), Np = dr_round_up(Cout, 32);
     float* wp = (float*)rt::dmalloc((size_t)taps * Kp * Np * sizeof(float));
     if (!wp) return DR_E_NOMEM;
-    DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, w, wp, taps, Cin, Cout, Kp, Np);
+    if (g_dbg_bf16) DR_LAUNCH(pack_weights_bf16_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, w, (__bf16*)wp, taps, Cin, Cout, Kp, Np);
+    else DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, w, wp, taps, Cin, Cout, Kp, Np);
     ConvParams p{};
+    p.bf16 = g_dbg_bf16;
     p.x = x; p.x_cs = x_cs; p.x_coff = 0; p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.ksize = k;
     p.w = wp; p.Kp = Kp; p.Np = Np; p.y = y; p.y_cs = y_cs; p.y_coff = 0; p.Cout = Cout;
     p.scale = scale; p.shift = shift; p.relu = relu; p.res = res; p.res_cs = res_cs; p.res_coff = 0;
@@ -1315,6 +1373,11 @@ extern "C" int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, 
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
     for (auto& v : hx) v = abl == 6 ? 0.f : rnd();          // abl 6: all-zero operands (DVFS best case)
     for (auto& v : hw) v = abl == 6 ? 0.f : rnd() * 0.05f;
+    const bool bf = g_dbg_bf16 && abl == 0;
+    if (bf) {                                               // the same buffer as bf16 elements: truncated small floats
+        uint16_t* hb = reinterpret_cast<uint16_t*>(hw.data());
+        for (size_t i = 0; i < hw.size() * 2; ++i) { const float f = rnd() * 0.05f; uint32_t u; memcpy(&u, &f, 4); hb[i] = (uint16_t)(u >> 16); }
+    }
     rt::h2d(x, hx.data(), hx.size() * sizeof(float), nullptr);
     rt::h2d(wp, hw.data(), hw.size() * sizeof(float), nullptr);
     rt::h2d(sc, hs.data(), hs.size() * sizeof(float), nullptr);
@@ -1322,6 +1385,7 @@ extern "C" int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, 
     ConvParams p{};
     p.x = x; p.x_cs = x_cs; p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.ksize = k;
     p.w = wp; p.Kp = Kp; p.Np = Np; p.y = y; p.y_cs = y_cs; p.Cout = Cout; p.scale = sc; p.shift = sc; p.relu = 1;
+    if (bf) { p.bf16 = 1; p.Kp = dr_round_up(Cin, 32); }
     float* zeros = (float*)rt::dmalloc(256);
     if (!zeros) return DR_E_NOMEM;
     rt::memset_async(zeros, 0, 256, nullptr);
@@ -1417,6 +1481,12 @@ extern "C" int dr_dbg_mfma_peak(int iters, int waves_per_simd, int zero_data, fl
 extern "C" int dr_dbg_force_tile(int tile) {
     if (tile < -1 || tile > KID_CONV_64x64_K64) return DR_E_INVALID;
     g_force_tile = tile;
+    return DR_OK;
+}
+
+// dr_dbg_conv2d and dr_dbg_conv_bench (abl 0) run the bf16 matrix-core kernels while on (process-global)
+extern "C" int dr_dbg_force_bf16(int on) {
+    g_dbg_bf16 = on ? 1 : 0;
     return DR_OK;
 }
 

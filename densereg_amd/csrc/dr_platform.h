@@ -106,6 +106,8 @@ __device__ __forceinline__ void dr_glds16(const float* src, float* lds_wave_base
 #endif
 
 typedef float dr_f32x16 __attribute__((ext_vector_type(16)));
+typedef float dr_f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 dr_bf16x8 __attribute__((ext_vector_type(8)));      // one operand of v_mfma_f32_32x32x16_bf16
 typedef float dr_f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ static inline int dr_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -138,6 +138,7 @@ struct dr_handle {
     std::vector<GraphEntry> graphs;
     hipStream_t cap_stream = nullptr;                      // library-owned stream the captures are recorded on
     bool use_graphs = false;
+    int precision = 0;                                      // dr_set_precision: 0 = fp32 MFMA, 1 = bf16 MFMA (inference handles)
     bool fuse_bn_bwd = true;                               // DR_FUSE_BN_BWD=0: every BatchReNorm layer runs its own reduce pass
     bool multi_stream = false;                             // DR_MULTI_STREAM=1 turns the lanes on; off or profiling: every lane = caller's stream
     float* tiny = nullptr;                                  // (B,h,w) normalised depth at map resolution

@@ -51,6 +51,11 @@ class Engine:
     def close(self):
         self.h.close()
 
+    def set_precision(self, precision: str):
+        """'f32' (default) or 'bf16': matrix-core arithmetic of the eval-mode convolutions (dr_set_precision).
+        Inference engines only; call before load_params (it un-finalizes the handle)."""
+        self.h.call('dr_set_precision', {'f32': 0, 'bf16': 1}[precision])
+
     def load_params(self, params: Dict[str, np.ndarray]):
         self.h.load_params(params)
         self.h.call('dr_finalize_params', self._stream())

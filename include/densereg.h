@@ -153,6 +153,16 @@ int dr_flat_adam(dr_handle* h, float** m_dev_ptr, float** v_dev_ptr, size_t* cou
  * weights for the next forward. */
 int dr_apply_adam(dr_handle* h, float lr, float div, float clip, int64_t step, dr_stream stream);
 
+/* ---- precision ------------------------------------------------------------------------------------ */
+/* Matrix-core arithmetic of the convolutions of dr_forward_eval / dr_infer (BASELINE config 5 asks for a bf16 MFMA
+ * conv path): DR_PREC_F32 (default) = v_mfma_f32_32x32x2_f32; DR_PREC_BF16 = activations and weights rounded to bf16
+ * (nearest even) as they enter the matrix cores, fp32 accumulation, fp32 tensors, epilogues, heads' outputs and vote.
+ * Inference handles only (training=0 -> DR_E_UNSUPPORTED otherwise).  Call before dr_finalize_params: changing the
+ * precision un-finalizes the handle because the packed weights change type. */
+#define DR_PREC_F32 0
+#define DR_PREC_BF16 1
+int dr_set_precision(dr_handle* h, int precision);
+
 /* ---- introspection (tests / profiling) ----------------------------------------------------------- */
 /* Post-activation output of conv `scope` (e.g. "Conv_12") of the last forward as dense NHWC. */
 int dr_read_activation(dr_handle* h, const char* scope, int B, float* host, size_t count);

@@ -42,6 +42,10 @@ int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, int tile, i
  * v_mfma_f32_32x32x2_f32; `waves_per_simd` resident waves; zero_data = 1 feeds zeros, the DVFS best case). */
 int dr_dbg_mfma_peak(int iters, int waves_per_simd, int zero_data, float* tflops_out);
 
+/* While on (process-global), dr_dbg_conv2d and dr_dbg_conv_bench (abl 0) pack their weights as bf16 and run the
+ * bf16 matrix-core variant of the tile (dr_set_precision(DR_PREC_BF16) on a handle). */
+int dr_dbg_force_bf16(int on);
+
 /* Force the conv tile of every following launch (-1 = heuristic; ids as in dr_dbg_conv_bench).
  * Process-global; tests use it to check every tile shape against the reference. */
 int dr_dbg_force_tile(int tile);

@@ -85,8 +85,11 @@ class TorchOps(OpsBase):
 
     def __init__(self, cfg: NetConfig, params: Dict[str, torch.Tensor], is_training: bool,
                  dropout_masks: Optional[List[torch.Tensor]] = None, dtype=torch.float32,
-                 record: Optional[dict] = None):
+                 record: Optional[dict] = None, conv_operands: str = 'f32'):
         super().__init__(cfg)
+        # 'bf16': what a bf16 matrix-core path computes (BASELINE config 5; include/densereg.h dr_set_precision) --
+        # both operands of every k != 7 convolution rounded to bfloat16 (nearest even), products and sums in fp32
+        self.conv_operands = conv_operands
         self.p = params
         self.is_training = is_training
         self.dropout_masks = dropout_masks
@@ -132,6 +135,9 @@ class TorchOps(OpsBase):
         pt, pb = same_pad(H, k, stride)
         pl, pr = same_pad(W, k, stride)
         xp = F.pad(x, (pl, pr, pt, pb)) if (pt or pb or pl or pr) else x
+        if self.conv_operands == 'bf16' and k != 7:          # the 1-channel stem stays on the fp32 direct kernel
+            xp = xp.to(torch.bfloat16).to(xp.dtype)
+            w = w.to(torch.bfloat16).to(w.dtype)
         y = F.conv2d(xp, w.permute(3, 2, 0, 1), stride=stride)
         if bn:
             y = self._batch_renorm(y, name)
@@ -209,10 +215,10 @@ def to_torch_params(params: Dict[str, np.ndarray], dtype=torch.float32, requires
 
 
 def detect_net(cfg: NetConfig, tparams, dm_nhwc: torch.Tensor, is_training: bool,
-               dropout_masks=None, record=None):
+               dropout_masks=None, record=None, conv_operands='f32'):
     """um_v1.detect_net: dm (B,H,W,1) normalised -> end_points with NHWC tensors + TorchOps."""
     dtype = dm_nhwc.dtype
-    ops = TorchOps(cfg, tparams, is_training, dropout_masks, dtype, record)
+    ops = TorchOps(cfg, tparams, is_training, dropout_masks, dtype, record, conv_operands)
     hm, hm3, um = walk_detect_net(ops, dm_nhwc.permute(0, 3, 1, 2))
     nhwc = lambda t: t.permute(0, 2, 3, 1)
     return {'hm_outs': [nhwc(t) for t in hm], 'hm3_outs': [nhwc(t) for t in hm3],
@@ -220,11 +226,11 @@ def detect_net(cfg: NetConfig, tparams, dm_nhwc: torch.Tensor, is_training: bool
 
 
 def forward_eval(cfg: NetConfig, params: Dict[str, np.ndarray], dm: np.ndarray, dtype=torch.float32,
-                 record=None):
+                 record=None, conv_operands='f32'):
     """Eval-mode forward; returns dict of lists of NHWC numpy arrays."""
     with torch.no_grad():
         tp = to_torch_params(params, dtype)
-        ep, _ = detect_net(cfg, tp, torch.from_numpy(dm).to(dtype), False, record=record)
+        ep, _ = detect_net(cfg, tp, torch.from_numpy(dm).to(dtype), False, record=record, conv_operands=conv_operands)
     return {k: [t.contiguous().numpy() for t in v] for k, v in ep.items()}
 
 

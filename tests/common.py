@@ -191,6 +191,12 @@ def ref_conv2d(x, w, scale=None, shift=None, relu=False, res=None, rowmask=None,
     return y.numpy(), raw.numpy()
 
 
+def bf16_round(a):
+    """fp32 -> bfloat16 (round to nearest even) -> fp32: what enters the bf16 matrix cores."""
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

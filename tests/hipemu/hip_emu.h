@@ -67,7 +67,7 @@ struct Wave {
     int alive = 0;
     // two slot banks, alternated per collective: a lane can be at most one collective ahead of the
     // slowest lane of its wave, so one rendezvous per collective is enough (write bank p, sync, read).
-    alignas(16) uint32_t slot[2][kWave][4];
+    alignas(16) uint32_t slot[2][kWave][8];
 };
 
 struct Block {
@@ -237,6 +237,31 @@ static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float 
             std::memcpy(&av, &w.slot[bank][i + 32 * k][0], 4);
             std::memcpy(&bv, &w.slot[bank][j + 32 * k][1], 4);
             acc = std::fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+
+// v_mfma_f32_32x32x16_bf16 (gfx950): lane l holds 8 bf16 of row l&31, k = 8*(l>>5) + 0..7, for both operands; D as above.
+// Products of two bf16 are exact in fp32; the accumulation order inside the instruction is not architected (k order here).
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c, int, int, int) {
+    hipemu::Wave& w = hipemu::my_wave();
+    int l = hipemu::lane_id();
+    const unsigned bank = (hipemu::cur_fiber().coll++) & 1u;
+    std::memcpy(&w.slot[bank][l][0], &a, 16);
+    std::memcpy(&w.slot[bank][l][4], &b, 16);
+    hipemu::sync_wave();
+    auto bf = [](uint32_t word, int half) { uint32_t u = (half ? (word >> 16) : (word & 0xFFFFu)) << 16; float f; std::memcpy(&f, &u, 4); return f; };
+    hipemu_f32x16 d = c;
+    int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            const int src = 32 * (k >> 3), e = k & 7;
+            acc = std::fmaf(bf(w.slot[bank][i + src][e >> 1], e & 1), bf(w.slot[bank][j + src][4 + (e >> 1)], e & 1), acc);
         }
         d[r] = acc;
     }

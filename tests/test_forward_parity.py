@@ -10,7 +10,7 @@ and BASELINE.json's <= 0.1 mm mean-joint-error delta end to end.
 import numpy as np
 import pytest
 
-from tests.common import e2e_case, golden, ref_conv2d
+from tests.common import bf16_round, e2e_case, golden, ref_conv2d
 
 BACKENDS = [pytest.param('emu'), pytest.param('gpu', marks=pytest.mark.gpu)]
 
@@ -119,6 +119,40 @@ def test_conv_lds_dma_refill_variant(be, monkeypatch):
         outs.append(y)
 
 
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
+def test_conv_bf16_matrix_core_variant(be, tile):
+    """BF kernels (v_mfma_f32_32x32x16_bf16, conv_igemm.h): both operands rounded to bf16 as they are staged, fp32
+    accumulation and epilogue.  Reference = the fp64 conv of the bf16-rounded operands, so what is left is fp32
+    summation order (products of two bf16 are exact in fp32).  Shapes: ragged Cin on both sides of the 4-channel
+    half slot (37, 67, 515-like 35), a short last 32-channel K-tile, a single K-tile, row mask, residual, poison in
+    the padding channels."""
+    rng = np.random.default_rng(100 + tile)
+    np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32}[tile]
+    Cout = np_needed - 3
+    try:
+        assert be.lib.dr_dbg_force_tile(tile) == 0 and be.lib.dr_dbg_force_bf16(1) == 0
+        for (cin, k, hw, extras) in ((37, 3, (9, 15), True), (67, 1, (4, 5), True), (35, 3, (5, 4), False), (64, 3, (8, 8), True),
+                                     (12, 1, (3, 7), False), (96, 1, (6, 6), False), (6, 3, (4, 4), False)):
+            x = rng.standard_normal((2,) + hw + (cin,)).astype(np.float32)
+            w = (rng.standard_normal((k, k, cin, Cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+            scale = shift = res = mask = None
+            if extras:
+                scale = (0.5 + rng.random(Cout)).astype(np.float32)
+                shift = rng.standard_normal(Cout).astype(np.float32)
+                res = rng.standard_normal((2,) + hw + (Cout,)).astype(np.float32)
+                if k == 1:                                   # the network masks rows of 1x1 convs only (um_v1.py:146-148)
+                    mask = np.where(rng.random((2,) + hw) < 0.3, -1.0, 0.5).astype(np.float32)
+            y = be.conv2d(x, w, scale, shift, extras, res, mask, -0.5)
+            yr, _ = ref_conv2d(bf16_round(x), bf16_round(w), scale, shift, extras, res, mask, -0.5)
+            assert _rel(y, yr) < 2e-5, (cin, k)
+            # and it IS the bf16 path: the fp32 result differs by the operand rounding (~2^-9 relative)
+            y32, _ = ref_conv2d(x, w, scale, shift, extras, res, mask, -0.5)
+            assert 1e-4 < _rel(y, y32) < 3e-2, (cin, k, _rel(y, y32))
+    finally:
+        be.lib.dr_dbg_force_tile(-1)
+        be.lib.dr_dbg_force_bf16(0)
+
+
 def test_conv_plain_linear(be):
     rng = np.random.default_rng(5)
     x = rng.standard_normal((2, 5, 5, 24)).astype(np.float32)
@@ -176,6 +210,59 @@ def test_network_forward_and_vote_config1(be, case1):
     assert pose.mean_jnt_error(xyz2, g['xyz']) <= 0.1           # BASELINE.json tolerance
     assert np.abs(xyz2 - g['xyz']).max() < 0.05
     h.close()
+
+
+def test_network_bf16_precision(be, case1):
+    """dr_set_precision(DR_PREC_BF16) (BASELINE config 5's "bf16 MFMA conv path"): every k != 7 conv rounds both
+    operands to bf16 on their way into the matrix cores.  Two bf16 evaluations with different fp32 summation orders
+    decorrelate (a 1e-7 difference flips a rounding of 2^-9), so the network-level statement is about noise, not
+    bits: per conv output and per head map the engine is (a) closer to the oracle's bf16-operand evaluation than that
+    evaluation is to fp32, and (b) no further from fp32 than the oracle's bf16 evaluation is (x1.25) -- i.e. it
+    carries the precision's own error and nothing else.  Kernel-level exactness is test_conv_bf16_matrix_core_variant.
+    The vote runs in fp32 on whatever maps it is given (test_network_forward_and_vote_config1)."""
+    from oracle import net
+    from oracle.graph import conv_specs
+    cfg, params, g = case1
+    h = be.handle(cfg, 1)
+    h.call('dr_set_precision', 1)
+    h.load_params(params)
+    h.call('dr_finalize_params', be.stream)
+    ndm = be.norm_dm(h, g['dm'], g['com'])
+    hm, hm3, um = be.forward_eval(h, ndm)
+    rec16, rec32 = {}, {}
+    o16 = net.forward_eval(cfg, params, ndm, record=rec16, conv_operands='bf16')
+    o32 = net.forward_eval(cfg, params, ndm, record=rec32)
+    l2 = lambda a, b: float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(np.asarray(b).ravel()) + 1e-12))
+
+    def check(a, r16, r32, what):
+        e_eng16, e_prec, e_eng32 = l2(a, r16), l2(r16, r32), l2(a, r32)
+        assert e_eng16 <= e_prec + 1e-5, (what, e_eng16, e_prec)
+        assert e_eng32 <= 1.25 * e_prec + 1e-5, (what, e_eng32, e_prec)
+        return e_eng32
+
+    worst = 0.0
+    for c in conv_specs(cfg):
+        a = be.read_activation(h, c.name, (1, c.h_out, c.w_out, c.cout))
+        key = c.name + '+res' if c.name + '+res' in rec16 else c.name
+        worst = max(worst, check(a, rec16[key], rec32[key], c.name))
+    for k, a in (('hm_outs', hm), ('hm3_outs', hm3), ('um_outs', um)):
+        check(a, o16[k][-1], o32[k][-1], k)
+    assert 1e-3 < worst < 0.15, worst                      # it is bf16 (not fp32), and it is not garbage
+    # switching back re-packs fp32 weights and reproduces the fp32 maps
+    h.call('dr_set_precision', 0)
+    with pytest.raises(Exception):
+        be.forward_eval(h, ndm)                            # un-finalized by the precision change
+    h.call('dr_finalize_params', be.stream)
+    hm_b, _, _ = be.forward_eval(h, ndm)
+    assert np.abs(hm_b[:, ::2, ::2] - g['hm']).max() < 2e-4
+    h.close()
+    # training handles keep fp32 matrix cores
+    ht = be.handle(cfg, 1, training=True)
+    with pytest.raises(Exception):
+        ht.call('dr_set_precision', 1)
+    with pytest.raises(Exception):
+        ht.call('dr_set_precision', 7)
+    ht.close()
 
 
 def test_vote_crafted_cases(be):

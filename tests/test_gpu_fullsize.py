@@ -131,6 +131,17 @@ def test_input_256_maps_64_forward_and_vote(gpu):
     xyz = gpu.infer(h, ndm, cfgs, coms)
     ref = pose.estimate_pose_mm(ep['hm_outs'][-1], ep['hm3_outs'][-1], ep['um_outs'][-1], ndm, cfgs, coms, out_hw=64)
     assert pose.mean_jnt_error(xyz, ref) <= 0.1
+    # the same geometry on the bf16 matrix cores (config 5 names a bf16 MFMA conv path): carries the precision's own
+    # error and nothing else (tests/test_forward_parity.py::test_network_bf16_precision states the criterion)
+    h.call('dr_set_precision', 1)
+    h.call('dr_finalize_params', gpu.stream)
+    maps16 = gpu.forward_eval(h, ndm)
+    ep16 = net.forward_eval(cfg, params, ndm, conv_operands='bf16')
+    l2 = lambda a, b: float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-12))
+    for got, key in zip(maps16, ('hm_outs', 'hm3_outs', 'um_outs')):
+        e_prec = l2(ep16[key][-1], ep[key][-1])
+        assert l2(got, ep16[key][-1]) <= e_prec + 1e-5 and l2(got, ep[key][-1]) <= 1.25 * e_prec + 1e-5, key
+        assert 1e-4 < e_prec < 0.2, (key, e_prec)
     h.close()
 
 

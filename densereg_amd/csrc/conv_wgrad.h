@@ -438,56 +438,63 @@ __global__ __launch_bounds__(256) void wgrad_fold_all_kernel(const float* slabs,
     if (sl == 0 && i < sg.n) grad[sg.dst_off + i] += (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
-// Stem (7x7/s2, Cin = 1): dW[ky][kx][n] = sum_pix x[b, oy*s+ky-pt, ox*s+kx-pl] * g[pix][n], Cout = 32.
-// block = 256 threads = 8 tap groups x 32 channels over a chunk of `chunk` output pixels; it writes one partial
-// row [k*k][32] (tap-major) that wgrad_reduce_kernel folds into the flat gradient -- no floating-point atomics.
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* x, int B, int H, int W, const float* g, int g_cs, int k,
-                                                         int stride, int pad_t, int pad_l, int Ho, int Wo, int chunk, float* partial) {
-    const int n = threadIdx.x & 31, tg = threadIdx.x >> 5;
-    const int M = B * Ho * Wo, HWo = Ho * Wo;
-    const int m0 = blockIdx.x * chunk;
-    const int m1 = m0 + chunk < M ? m0 + chunk : M;
-    float acc[7];
-    int ty[7], tx[7];
+// Stem (um_v1.py:86: 7x7 / stride 2, Cin = 1, Cout = 32): dW[ky][kx][n] = sum_pix x[b, 2*oy+ky-pt, 2*ox+kx-pl] * g[pix][n].
+// A unit is 64 consecutive output pixels of one output row.  The workgroup stages the unit's input window (7 rows x 133
+// columns, zero outside the image) and its 64 x 32 gradient rows in LDS once; thread (ky, n) then walks the 64 pixels
+// with a sliding 7-wide register window over row ky -- per pixel two new LDS words (broadcast within the 32 lanes of a
+// ky) and one gradient word feed 7 FMAs.  (The previous version issued 8 global loads per 7 FMAs: 221 us for 0.5 GFLOP.)
+// A workgroup accumulates `units_per_wg` units in registers and writes one partial row [7*7][32] (tap-major) that
+// wgrad_reduce_kernel folds into the flat gradient -- no floating-point atomics.
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* x, int B, int H, int W, const float* g, int g_cs, int pad_t,
+                                                         int pad_l, int Ho, int Wo, int units_per_wg, float* partial) {
+    constexpr int K = 7, S = 2, PX = 64, XW = S * (PX - 1) + K;          // 133 input columns under 64 output pixels
+    __shared__ float xs[K][XW + 3];
+    __shared__ __attribute__((aligned(16))) float gs[PX][32];
+    const int tid = threadIdx.x, n = tid & 31, ky = tid >> 5;             // ky = 7: staging only
+    const int nseg = Wo / PX;
+    const int units = B * Ho * nseg;
+    float acc[K];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        acc[i] = 0.f;
-        const int tap = tg + 8 * i;
-        ty[i] = tap / k - pad_t; tx[i] = tap % k - pad_l;
-    }
-    // pixels in groups of 8: the eight gradient rows and then, per tap, the eight input pixels are loaded as
-    // independent batches (one pixel per iteration was a chain of dependent HBM round trips: 333 us for 0.5 GFLOP)
-    constexpr int U = 8;
-    for (int mg = m0; mg < m1; mg += U) {
-        float gv[U];
-        int by[U], bx[U], bo[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int m = mg + u < m1 ? mg + u : m1 - 1;                  // tail: re-read the last pixel, weight 0
-            gv[u] = mg + u < m1 ? g[(long)m * g_cs + n] : 0.f;
-            const int b = m / HWo, rem = m % HWo;
-            by[u] = (rem / Wo) * stride; bx[u] = (rem % Wo) * stride; bo[u] = b * H * W;
+    for (int kx = 0; kx < K; ++kx) acc[kx] = 0.f;
+    for (int uu = 0; uu < units_per_wg; ++uu) {
+        const int u = blockIdx.x * units_per_wg + uu;
+        if (u >= units) break;                                            // uniform
+        const int seg = u % nseg, r = u / nseg, oy = r % Ho, b = r / Ho;
+        const int ix0 = seg * PX * S - pad_l, iy0 = oy * S - pad_t;
+        __syncthreads();                                                  // the previous unit's readers are done
+        for (int i = tid; i < K * XW; i += 256) {
+            const int yy = i / XW, xx = i - yy * XW;
+            const int iy = iy0 + yy, ix = ix0 + xx;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float v = x[ok ? ((long)b * H + iy) * W + ix : 0];
+            xs[yy][xx] = ok ? v : 0.f;
         }
+        const long m0 = (long)r * Wo + seg * PX;
+        for (int i = tid; i < PX * 8; i += 256) {
+            const int px = i >> 3, c4 = (i & 7) * 4;
+            *reinterpret_cast<float4*>(&gs[px][c4]) = *reinterpret_cast<const float4*>(g + (m0 + px) * g_cs + c4);
+        }
+        __syncthreads();
+        if (ky < K) {
+            float win[K + 2];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            if (tg + 8 * i >= k * k) break;
-            float xv[U];
+            for (int kx = 0; kx < K - 2; ++kx) win[kx] = xs[ky][kx];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int iy = by[u] + ty[i], ix = bx[u] + tx[i];
-                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                xv[u] = x[ok ? bo[u] + iy * W + ix : 0];
-                if (!ok) xv[u] = 0.f;
+            for (int ox = 0; ox < PX; ++ox) {
+                win[K - 2] = xs[ky][S * ox + K - 2];
+                win[K - 1] = xs[ky][S * ox + K - 1];
+                const float gv = gs[ox][n];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) acc[kx] = fmaf(win[kx], gv, acc[kx]);
+#pragma unroll
+                for (int kx = 0; kx < K - 2; ++kx) win[kx] = win[kx + 2];
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) acc[i] = fmaf(xv[u], gv[u], acc[i]);
         }
     }
-    float* row = partial + (long)blockIdx.x * k * k * 32;
+    if (ky < K) {
+        float* row = partial + (long)blockIdx.x * K * K * 32;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int tap = tg + 8 * i;
-        if (tap < k * k) row[tap * 32 + n] = acc[i];
+        for (int kx = 0; kx < K; ++kx) row[(ky * K + kx) * 32 + n] = acc[kx];
     }
 }
 

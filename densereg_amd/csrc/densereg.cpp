@@ -8,6 +8,7 @@
 #include "conv_igemm.h"
 #include "conv_wgrad.h"
 #include "frontend.h"
+#include "dataio.h"
 #include "kernels_misc.h"
 #include "net.h"
 #include "train_kernels.h"
@@ -908,6 +909,19 @@ int dr_data_aug(int B, const float* dms, int H, int W, const float* pose, int J,
     p.dms = dms; p.H = H; p.W = W; p.pose = pose; p.J = J; p.cfg = cfg; p.com = com; p.draws = draws;
     p.out_dms = out_dms; p.out_pose = out_pose;
     DR_LAUNCH(data_aug_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p);
+    std::string m;
+    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
+}
+
+int dr_png_unfilter(const uint8_t* filtered, int height, int row_bytes, int bpp, uint8_t* out) {
+    if (!filtered || !out || height < 1 || row_bytes < 1 || bpp < 1 || bpp > 8) return DR_E_INVALID;
+    return png_unfilter_host(filtered, height, row_bytes, bpp, out) ? DR_E_INVALID : DR_OK;
+}
+
+int dr_depth_from_samples(const uint8_t* samples_dev, long npix, int mode, float* depth_dev, dr_stream stream) {
+    if (!samples_dev || !depth_dev || npix < 1 || (mode != DR_SAMPLES_RGB8_GB && mode != DR_SAMPLES_GREY16_BE)) return DR_E_INVALID;
+    if (((uintptr_t)samples_dev & 3) || ((uintptr_t)depth_dev & 15)) return DR_E_INVALID;
+    DR_LAUNCH(depth_unpack_kernel, dim3(grid_for((npix + 3) / 4, 256, 1 << 30)), dim3(256), 0, (hipStream_t)stream, samples_dev, npix, mode, depth_dev);
     std::string m;
     return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
 }

@@ -38,6 +38,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--max_steps', type=int, default=0, help='stop after this many optimizer steps (0 = the reference schedule)')
     p.add_argument('--num_frames', type=int, default=0, help='test: number of synthetic frames (0 = dataset exact_num)')
     p.add_argument('--seed', type=int, default=20240)
+    p.add_argument('--data_dir', default='', help='dataset root holding the TFRecord shards (exp/data/<dataset>/ in the reference); '
+                   'empty = seeded synthetic crops')
     p.add_argument('--restore_step', type=int, default=0, help='restore <train_dir>/model.ckpt-<step> (TF V2 checkpoint) before training / testing')
     p.add_argument('--save_every', type=int, default=0, help='train: write <train_dir>/model.ckpt-<step> every N optimizer steps and at the end (0 = never)')
     return p

@@ -96,6 +96,8 @@ class JointDetectionModel(object):
 
     # ---- the path ---------------------------------------------------------------------------------
     def _t(self, a):
+        if isinstance(a, torch.Tensor):                                     # record datasets hand over device tensors
+            return a.to(self.device, torch.float32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
 
     def inference(self, normed_dms, cfgs, coms, is_training=True):
@@ -176,7 +178,10 @@ def test_model(model: JointDetectionModel, out_path: str, log=sys.stdout):
     max_err, mean_err, n, step = [], [], 0, 0
     with open(out_path, 'w') as f:
         while n < total:
-            dm, poses, cfgs, coms, names = model._val_dataset.batch(F.batch_size, step)
+            try:
+                dm, poses, cfgs, coms, names = model._val_dataset.batch(F.batch_size, step)
+            except StopIteration:                                           # a record dataset shorter than exact_num
+                break
             xyz = model.test(model._t(dm), model._t(poses), model._t(cfgs), model._t(coms)).cpu().numpy()
             for xyz_val, gt_val, name in zip(xyz, poses, names):
                 max_err.append(Evaluation.maxJntError(xyz_val, gt_val))
@@ -234,8 +239,14 @@ def main(argv=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world)
     torch.cuda.set_device(local)
-    dataset = SyntheticDataset(F.dataset, 'training', rank)
-    val_dataset = SyntheticDataset(F.dataset, 'testing', rank)
+    if F.data_dir:                                                          # the reference's TFRecord shards (data/datasets.py)
+        from ..data.datasets import get_dataset
+        dataset = get_dataset(F.dataset, 'training', F.data_dir, F.pid)
+        val_dataset = get_dataset(F.dataset, 'testing', F.data_dir, F.pid)
+        dataset.rank, dataset.world, dataset.seed = rank, world, F.seed
+    else:
+        dataset = SyntheticDataset(F.dataset, 'training', rank)
+        val_dataset = SyntheticDataset(F.dataset, 'testing', rank)
     eng = um_v1.get_engine(dataset.jnt_num, 128, F.batch_size, local, bool(F.is_train))
     eng.load_params(_random_params(eng))
     if F.is_train:

@@ -153,6 +153,19 @@ int dr_flat_adam(dr_handle* h, float** m_dev_ptr, float** v_dev_ptr, size_t* cou
  * weights for the next forward. */
 int dr_apply_adam(dr_handle* h, float lr, float div, float clip, int64_t step, dr_stream stream);
 
+/* ---- dataset formats: PNG depth frames out of the TFRecord files --------------------------- */
+/* Host: undo the PNG row filters (PNG spec 9.2) of an inflated IDAT stream.  `filtered` = height rows of
+ * (1 filter-type byte + row_bytes), bpp = bytes per pixel (3 for NYU's RGB8, 2 for 16-bit grey); out = height*row_bytes
+ * bytes.  Replaces the filter stage of tf.image.decode_png (data/nyu.py:148-149, data/icvl.py, data/msra.py:190).
+ * DR_E_INVALID on an unknown filter type. */
+int dr_png_unfilter(const uint8_t* filtered, int height, int row_bytes, int bpp, uint8_t* out);
+/* Device: PNG samples -> fp32 depth frame in mm.  DR_SAMPLES_RGB8_GB: 3 bytes per pixel, depth = (G << 8) | B
+ * (data/nyu.py:151-156); DR_SAMPLES_GREY16_BE: 2 bytes per pixel, big-endian (decode_png(dtype=uint16) + to_float).
+ * samples_dev 4-byte aligned, depth_dev 16-byte aligned, npix pixels (any number of frames back to back). */
+#define DR_SAMPLES_RGB8_GB 0
+#define DR_SAMPLES_GREY16_BE 1
+int dr_depth_from_samples(const uint8_t* samples_dev, long npix, int mode, float* depth_dev, dr_stream stream);
+
 /* ---- precision ------------------------------------------------------------------------------------ */
 /* Matrix-core arithmetic of the convolutions of dr_forward_eval / dr_infer (BASELINE config 5 asks for a bf16 MFMA
  * conv path): DR_PREC_F32 (default) = v_mfma_f32_32x32x2_f32; DR_PREC_BF16 = activations and weights rounded to bf16

@@ -178,7 +178,11 @@ class BaseDataset(object):
         return preprocess.crop_and_com_from_pose(frames, poses, cfgs, out_hw, out_hw, dataset=self.name)
 
     def batches(self, batch_size: int, device, out_hw: int = 128, shuffle: Optional[bool] = None, seed: int = 0, rank: int = 0,
-                world: int = 1, epochs: Optional[int] = None, drop_last: bool = False, files: Optional[Sequence[str]] = None):
+                world: int = 1, epochs: Optional[int] = None, drop_last: bool = False, files: Optional[Sequence[str]] = None,
+                workers: int = 4):
+        """``workers`` host threads decode the frames of a batch concurrently (zlib and ``dr_png_unfilter`` release the
+        GIL; one thread decodes ~2600 ICVL or ~500 NYU frames/s, the training step consumes ~1700 crops/s:
+        ``profiles/r01_dataio_bench.md``) -- the reference's ``num_preprocess_threads``."""
         import torch
         shuffle = self.is_train if shuffle is None else shuffle
         pend = []
@@ -195,13 +199,21 @@ class BaseDataset(object):
             crops, _, new_cfgs, coms = self.preprocess(frames, d_pose, d_cfg, bbxs, out_hw)
             return crops.unsqueeze(-1), poses, new_cfgs, coms, [it[3] for it in items]
 
-        for rec in self.records(shuffle, seed, rank, world, epochs, files):
-            pend.append(self.parse_example(rec))
-            if len(pend) == batch_size:
-                yield flush(pend)
-                pend = []
-        if pend and not drop_last:
-            yield flush(pend)
+        pool = None
+        if workers > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(workers)
+        try:
+            for rec in self.records(shuffle, seed, rank, world, epochs, files):
+                pend.append(rec)
+                if len(pend) == batch_size:
+                    yield flush(list(pool.map(self.parse_example, pend)) if pool else [self.parse_example(r) for r in pend])
+                    pend = []
+            if pend and not drop_last:
+                yield flush(list(pool.map(self.parse_example, pend)) if pool else [self.parse_example(r) for r in pend])
+        finally:
+            if pool:
+                pool.shutdown(wait=False)
 
     def batch(self, batch_size: int, index: int, device=None):
         """The drivers' interface (``SyntheticDataset.batch``): the next batch of an endless (training) or single-pass,

@@ -7,6 +7,7 @@
 
 #include "conv_igemm.h"
 #include "conv_wgrad.h"
+#include "conv_wgrad_bf16.h"
 #include "frontend.h"
 #include "dataio.h"
 #include "kernels_misc.h"
@@ -219,6 +220,15 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* flat, float*
         const int t = int((i / (32l * sg.Np)) % sg.taps);
         const int k = int(i / (32l * sg.Np * sg.taps)) * 32 + kk;
         reinterpret_cast<__bf16*>(wp + sg.dst_off)[i] = (__bf16)((k < sg.Cin && n < sg.Cout) ? w[((long)t * sg.Cin + k) * sg.Cout + n] : 0.f);
+        return;
+    }
+    if (sg.transposed == 3) {                                   // bf16 dgrad packing: k = cout, n = cin, taps flipped
+        const int kk = int(i % 32);
+        const int n = int((i / 32) % sg.Np);
+        const int t = int((i / (32l * sg.Np)) % sg.taps);
+        const int k = int(i / (32l * sg.Np * sg.taps)) * 32 + kk;
+        reinterpret_cast<__bf16*>(wpT + sg.dst_off)[i] =
+            (__bf16)((k < sg.Cout && n < sg.Cin) ? w[((long)(sg.taps - 1 - t) * sg.Cin + n) * sg.Cout + k] : 0.f);
         return;
     }
     const int kk = int(i % 16);
@@ -781,6 +791,11 @@ static int repack_weights(dr_handle* h, hipStream_t s) {
                 const int Kp32 = dr_round_up(c.cin, 32);
                 segs.push_back(PackSeg{(long)c.w_off, (long)c.wp_off, taps, c.cin, c.cout, Kp32, c.Np, 2, blocks});
                 blocks += dr_ceil_div(taps * Kp32 * c.Np, 256);
+                if (h->cfg.training) {
+                    const int KpT32 = dr_round_up(c.cout, 32);
+                    segs.push_back(PackSeg{(long)c.w_off, (long)c.wpT_off, taps, c.cin, c.cout, KpT32, c.NpT, 3, blocks});
+                    blocks += dr_ceil_div(taps * KpT32 * c.NpT, 256);
+                }
                 continue;
             }
             segs.push_back(PackSeg{(long)c.w_off, (long)c.wp_off, taps, c.cin, c.cout, c.Kp, c.Np, 0, blocks});
@@ -819,8 +834,6 @@ static int fold_bn(dr_handle* h, hipStream_t s) {
 int dr_set_precision(dr_handle* h, int precision) {
     if (!h) return DR_E_INVALID;
     if (precision != DR_PREC_F32 && precision != DR_PREC_BF16) DR_FAIL(h, DR_E_INVALID, "dr_set_precision: unknown precision %d", precision);
-    if (precision == DR_PREC_BF16 && h->cfg.training)
-        DR_FAIL(h, DR_E_UNSUPPORTED, "dr_set_precision: the bf16 matrix-core path exists for inference handles (training=0)");
     if (precision != h->precision) {
         rt::sync_stream(nullptr);
         if (h->pack_dev) { rt::dfree(h->pack_dev); h->pack_dev = nullptr; }     // the packing table depends on the element type
@@ -1240,7 +1253,9 @@ extern "C" int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const
     p.B = B; p.H = H; p.W = W; p.ksize = k; p.rowmask = rowmask; p.mask_thresh = thresh;
     p.partial = partial; p.nsplit = nsplit; p.rows_per_split = rows;
     dim3 grid(dr_ceil_div(Cin, T) * dr_ceil_div(Cout, T) * taps * nsplit);
-    if (T == 96) DR_LAUNCH(conv_wgrad_row_kernel, dim3(3 * nsplit), dim3(256), 0, s, p);
+    if (g_dbg_bf16 && T == 128) DR_LAUNCH((conv_wgrad_bf16_kernel<128>), grid, dim3(256), 0, s, p);
+    else if (g_dbg_bf16 && T == 64) DR_LAUNCH((conv_wgrad_bf16_kernel<64>), grid, dim3(256), 0, s, p);
+    else if (T == 96) DR_LAUNCH(conv_wgrad_row_kernel, dim3(3 * nsplit), dim3(256), 0, s, p);
     else if (T == 128) DR_LAUNCH((conv_wgrad_kernel<128>), grid, dim3(256), 0, s, p);
     else DR_LAUNCH((conv_wgrad_kernel<64>), grid, dim3(256), 0, s, p);
     rt::memset_async(dw, 0, per * sizeof(float), s);

@@ -170,8 +170,9 @@ int dr_depth_from_samples(const uint8_t* samples_dev, long npix, int mode, float
 /* Matrix-core arithmetic of the convolutions of dr_forward_eval / dr_infer (BASELINE config 5 asks for a bf16 MFMA
  * conv path): DR_PREC_F32 (default) = v_mfma_f32_32x32x2_f32; DR_PREC_BF16 = activations and weights rounded to bf16
  * (nearest even) as they enter the matrix cores, fp32 accumulation, fp32 tensors, epilogues, heads' outputs and vote.
- * Inference handles only (training=0 -> DR_E_UNSUPPORTED otherwise).  Call before dr_finalize_params: changing the
- * precision un-finalizes the handle because the packed weights change type. */
+ * On a training handle the train-mode forward, the input-gradient and the weight-gradient convolutions follow
+ * (v_mfma_f32_32x32x16_bf16 in all three); BatchReNorm, loss, gradients, Adam and the master weights stay fp32.
+ * Call before dr_finalize_params: changing the precision un-finalizes the handle because the packed weights change type. */
 #define DR_PREC_F32 0
 #define DR_PREC_BF16 1
 int dr_set_precision(dr_handle* h, int precision);

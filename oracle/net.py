@@ -80,6 +80,27 @@ def init_params(cfg: NetConfig, seed: int = 7, reference_init: bool = False) -> 
     return out
 
 
+class _ConvBf16Operands(torch.autograd.Function):
+    """A convolution whose matrix-core operands are bfloat16 in all three products (include/densereg.h,
+    dr_set_precision): forward r(x) * r(w), input gradient r(gy) * r(w), weight gradient r(x) * r(gy), r = round to
+    nearest-even bfloat16, products and sums in the tensors' own precision.  The rounding itself has no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        r = lambda t: t.to(torch.bfloat16).to(t.dtype)
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return F.conv2d(r(x), r(w), stride=stride)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        r = lambda t: t.to(torch.bfloat16).to(t.dtype)
+        gx = torch.nn.grad.conv2d_input(x.shape, r(w), r(gy), stride=ctx.stride) if ctx.needs_input_grad[0] else None
+        gw = torch.nn.grad.conv2d_weight(r(x), w.shape, r(gy), stride=ctx.stride) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
 class TorchOps(OpsBase):
     """Computing backend for ``walk_detect_net``.  Tensors are NCHW torch tensors."""
 
@@ -136,9 +157,9 @@ class TorchOps(OpsBase):
         pl, pr = same_pad(W, k, stride)
         xp = F.pad(x, (pl, pr, pt, pb)) if (pt or pb or pl or pr) else x
         if self.conv_operands == 'bf16' and k != 7:          # the 1-channel stem stays on the fp32 direct kernel
-            xp = xp.to(torch.bfloat16).to(xp.dtype)
-            w = w.to(torch.bfloat16).to(w.dtype)
-        y = F.conv2d(xp, w.permute(3, 2, 0, 1), stride=stride)
+            y = _ConvBf16Operands.apply(xp, w.permute(3, 2, 0, 1), stride)
+        else:
+            y = F.conv2d(xp, w.permute(3, 2, 0, 1), stride=stride)
         if bn:
             y = self._batch_renorm(y, name)
         else:

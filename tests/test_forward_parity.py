@@ -256,10 +256,7 @@ def test_network_bf16_precision(be, case1):
     hm_b, _, _ = be.forward_eval(h, ndm)
     assert np.abs(hm_b[:, ::2, ::2] - g['hm']).max() < 2e-4
     h.close()
-    # training handles keep fp32 matrix cores
     ht = be.handle(cfg, 1, training=True)
-    with pytest.raises(Exception):
-        ht.call('dr_set_precision', 1)
     with pytest.raises(Exception):
         ht.call('dr_set_precision', 7)
     ht.close()

@@ -400,112 +400,14 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
         }
     if (ABL == 4 && abl_sink == 12345.678f) p.y[0] = abl_sink;
 
-    // ---- epilogue ----------------------------------------------------------------------------
-    // D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    // Every global read of the epilogue (output row mask, dropout keep bytes, residual) is issued as a batch of
-    // independent, unconditional loads BEFORE the first use (a masked-off lane reads element 0 and ignores it):
-    // written as "if (ok) v += res[...]" per element, hipcc serialises them behind s_waitcnt vmcnt(0) -- 16
-    // dependent HBM round trips per 32x32 tile, which was most of the run time of the short-K 1x1 layers.
-    // Indices are 32-bit element offsets from the (uniform) tensor base, so each access is "sgpr base + vgpr
-    // offset" and costs one address register; launch_conv_igemm rejects tensors of 2^32 elements or more.
+    // ---- epilogue: conv_epilogue.inc -------------------------------------------------------------
     double s1[T::kTN], s2[T::kTN];
 #pragma unroll
     for (int j = 0; j < T::kTN; ++j) s1[j] = s2[j] = 0.0;
-    const bool dropping = p.drop || p.drop_rng;
-#pragma unroll
-    for (int i = 0; i < T::kTM; ++i) {
-        const int mb = m0 + wm * T::kWTM + i * 32 + 4 * lk;               // row of r = 0
-        unsigned rows = 0;                                                  // bit r: this lane writes row r
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (mb + (r & 3) + 8 * (r >> 2) < M) rows |= 1u << r;
-        if (p.out_rowmask) {
-            float om[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) om[r] = p.out_rowmask[((rows >> r) & 1u) ? (unsigned)(mb + (r & 3) + 8 * (r >> 2)) : 0u];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (om[r] < p.out_mask_thresh) rows &= ~(1u << r);
-        }
-#pragma unroll
-        for (int j = 0; j < T::kTN; ++j) {
-            const int n = n0 + wn * T::kWTN + j * 32 + li;
-            const bool n_ok = n < p.Cout;
-            const float sc = (n_ok && p.scale) ? p.scale[n] : 1.f;
-            const float sh = (n_ok && p.shift) ? p.shift[n] : 0.f;
-            const unsigned rows_j = n_ok ? rows : 0u;
-            float b_sc = 0.f, b_sh = 0.f, b_mean = 0.f, b_istd = 0.f;    // BatchReNorm-backward statistics mode
-            if (p.bst_raw && n_ok) {
-                b_sc = p.bst_scale[n]; b_sh = p.bst_shift[n]; b_mean = p.bst_bnc[n]; b_istd = p.bst_bnc[p.Cout + n];
-            }
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {                         // 8 rows at a time: bounds the VGPR peak
-                float rv[8];
-                float braw[8];
-                unsigned keep = 0xFFu;
-                if (p.bst_raw) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int r = half * 8 + q;
-                        const unsigned m = (unsigned)(mb + (r & 3) + 8 * (r >> 2));
-                        braw[q] = p.bst_raw[((rows_j >> r) & 1u) ? m * (unsigned)p.bst_cs + (unsigned)n : 0u];
-                    }
-                }
-                if (p.res) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int r = half * 8 + q;
-                        const unsigned m = (unsigned)(mb + (r & 3) + 8 * (r >> 2));
-                        rv[q] = p.res[((rows_j >> r) & 1u) ? m * (unsigned)p.res_cs + (unsigned)(p.res_coff + n) : 0u];
-                    }
-                }
-                if (p.drop) {
-                    unsigned char dv[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int r = half * 8 + q;
-                        const unsigned m = (unsigned)(mb + (r & 3) + 8 * (r >> 2));
-                        dv[q] = p.drop[((rows_j >> r) & 1u) ? m * (unsigned)p.Cout + (unsigned)n : 0u];
-                    }
-                    keep = 0;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) keep |= (dv[q] ? 1u : 0u) << q;
-                } else if (p.drop_rng) {
-                    keep = 0;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int r = half * 8 + q;
-                        const unsigned long long m = (unsigned long long)(mb + (r & 3) + 8 * (r >> 2));
-                        keep |= (dropout_keep(p.drop_seed, m * p.Cout + n) ? 1u : 0u) << q;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int r = half * 8 + q;
-                    if (ABL == 3 && acc[i][j][r] != 12345.678f) continue;
-                    if ((rows_j >> r) & 1u) {
-                        const unsigned m = (unsigned)(mb + (r & 3) + 8 * (r >> 2));
-                        const float raw = acc[i][j][r];
-                        float v = raw * sc + sh;
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        if (dropping) v = ((keep >> q) & 1u) ? v * 2.f : 0.f;
-                        if (p.res) v += rv[q];
-                        p.y[m * (unsigned)p.y_cs + (unsigned)(p.y_coff + n)] = v;
-                        if (p.bst_raw) {
-                            float g = v;
-                            if (p.bst_relu && !(braw[q] * b_sc + b_sh > 0.f)) g = 0.f;
-                            const float yh = (braw[q] - b_mean) * b_istd;
-                            s1[j] += (double)g;
-                            s2[j] += (double)g * (double)yh;
-                        } else {
-                            s1[j] += (double)raw;
-                            s2[j] += (double)raw * (double)raw;
-                        }
-                    }
-                }
-            }
-        }
-    }
+    constexpr int EP_TM = T::kTM, EP_TN = T::kTN;
+    const int ep_m0 = m0 + wm * T::kWTM, ep_n0 = n0 + wn * T::kWTN;
+    const unsigned ep_rows = 0xFFFFu;
+#include "conv_epilogue.inc"
     if (p.stat_part) {
         // wave partials -> LDS (the operand tiles are dead: the K loop ended on a barrier) -> one row per workgroup
         double* red = reinterpret_cast<double*>(&As[0][0][0]);              // [2][WM][BN] doubles <= sizeof(As)

@@ -6,6 +6,7 @@
 #include <map>
 
 #include "conv_igemm.h"
+#include "conv_splitk.h"
 #include "conv_wgrad.h"
 #include "conv_wgrad_bf16.h"
 #include "frontend.h"
@@ -78,6 +79,10 @@ int conv_tile_id(const ConvParams& p) {
     // Grids that leave CUs idle (everything below 32x32 at B=40) are chains of ~0.6 us K-tiles with nothing to
     // overlap: the fat K-tile variant moves 64 channels per round trip (3x3 64->64 at 8x8: 22.8 -> see
     // profiles/r01_conv_microbench.md).  Needs >= 2 fat tiles to pay for its larger prologue.
+    // Below ~128 such workgroups (8x8 pixels and smaller at B = 40) even that leaves most of the chip idle while each wave
+    // issues the whole K axis: the split-K kernel (conv_splitk.h) quarters the chain and quadruples the workgroups
+    // (profiles/r01_conv_small_layers.md: 3x3 64->64 at 8x8 18.7 -> 10.9 us, 1x1 128->64 7.5 -> 5.5 us; at 16x16 it loses).
+    if (rows64 * dr_ceil_div(p.Np, 64) <= 128 && (long)p.ksize * p.ksize * dr_ceil_div(p.Kp, p.bf16 ? 32 : 16) >= 4) return KID_CONV_SPLITK;
     if (!p.bf16 && p.Np % 64 == 0 && rows64 * (p.Np / 64) <= 256 && (long)p.ksize * p.ksize * p.Kp >= 128) return KID_CONV_64x64_K64;
     if (p.Np % 128 == 0) {
         const long b128 = rows128 * (p.Np / 128), b64x128 = rows64 * (p.Np / 128), b64x64 = rows64 * (p.Np / 64);
@@ -93,6 +98,7 @@ int conv_tile_id(const ConvParams& p) {
 int conv_stat_rows(const ConvParams& p) {
     const int M = p.B * p.H * p.W;
     const int t = conv_tile_id(p);
+    if (t == KID_CONV_SPLITK) return dr_ceil_div(M, 32);
     return dr_ceil_div(M, (t == KID_CONV_64x128 || t == KID_CONV_64x64 || t == KID_CONV_64x64_K64) ? 64 : 128);
 }
 
@@ -102,6 +108,13 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     const long long M = (long long)p.B * p.H * p.W;
     const long long widest = std::max(std::max((long long)p.x_cs, (long long)p.y_cs), std::max((long long)p.res_cs, (long long)p.Cout));
     if (M * widest >= (1ll << 32)) return -1;
+    if (conv_tile_id(p) == KID_CONV_SPLITK) {
+        if (p.bf16 && p.Kp % 32) return -1;
+        dim3 grid(dr_ceil_div((int)M, 32), dr_ceil_div(p.Np, 32));
+        if (p.bf16) DR_LAUNCH((conv_splitk_kernel<1>), grid, dim3(256), 0, s, p);
+        else DR_LAUNCH((conv_splitk_kernel<0>), grid, dim3(256), 0, s, p);
+        return 0;
+    }
     if (p.bf16) {
         if (p.Kp % 32) return -1;
         switch (conv_tile_id(p)) {
@@ -1215,7 +1228,7 @@ extern "C" int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, cons
     p.rowmask = rowmask; p.mask_thresh = thresh;
     double* part = nullptr;
     if (stat) {
-        part = (double*)rt::dmalloc((size_t)dr_ceil_div(B * H * W, 64) * 2 * Cout * sizeof(double));
+        part = (double*)rt::dmalloc((size_t)dr_ceil_div(B * H * W, 32) * 2 * Cout * sizeof(double));   // 32-row tiles at most
         if (!part) return DR_E_NOMEM;
         p.stat_part = part;
     }
@@ -1508,7 +1521,7 @@ extern "C" int dr_dbg_mfma_peak(int iters, int waves_per_simd, int zero_data, fl
 
 // force the conv tile choice of every following launch (-1 = heuristic); tests sweep all tile shapes with it
 extern "C" int dr_dbg_force_tile(int tile) {
-    if (tile < -1 || tile > KID_CONV_64x64_K64) return DR_E_INVALID;
+    if (tile < -1 || tile > KID_CONV_SPLITK) return DR_E_INVALID;
     g_force_tile = tile;
     return DR_OK;
 }

@@ -38,6 +38,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--max_steps', type=int, default=0, help='stop after this many optimizer steps (0 = the reference schedule)')
     p.add_argument('--num_frames', type=int, default=0, help='test: number of synthetic frames (0 = dataset exact_num)')
     p.add_argument('--seed', type=int, default=20240)
+    p.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
+                   help='matrix-core arithmetic of the convolutions (dr_set_precision); the reference is fp32')
     p.add_argument('--data_dir', default='', help='dataset root holding the TFRecord shards (exp/data/<dataset>/ in the reference); '
                    'empty = seeded synthetic crops')
     p.add_argument('--restore_step', type=int, default=0, help='restore <train_dir>/model.ckpt-<step> (TF V2 checkpoint) before training / testing')

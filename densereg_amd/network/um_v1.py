@@ -28,10 +28,13 @@ def get_engine(num_jnt: int, in_hw: int, max_batch: int, device: int, training: 
     """One engine per (config, device); flags are read when the engine is first needed, like the
     reference reads ``FLAGS.num_stack/num_fea/kernel_size`` at graph-build time (um_v1.py:40,56,93,124)."""
     F = flags.FLAGS
-    key = (F.num_stack, F.num_fea, num_jnt, in_hw, F.kernel_size, device, training)
+    precision = getattr(F, 'precision', 'f32')
+    key = (F.num_stack, F.num_fea, num_jnt, in_hw, F.kernel_size, device, training, precision)
     eng = _engines.get(key)
     if eng is None or eng.max_batch < max_batch:
         eng = Engine(F.num_stack, F.num_fea, num_jnt, in_hw, F.kernel_size, max_batch, device, training)
+        if precision != 'f32':
+            eng.set_precision(precision)                 # before any load_params: the packed weights follow the precision
         _engines[key] = eng
     return eng
 

@@ -57,6 +57,30 @@ def test_conv_fused_epilogue(be, case):
     np.testing.assert_allclose(st[1], (raw ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_splitk_kernel_fused_epilogue(be, case):
+    """conv_splitk_kernel (32x32 output tile, the four waves split K and reduce through LDS; conv_splitk.h) with every
+    fused epilogue feature, incl. the BatchReNorm statistics whose partial rows now come four to a workgroup.  Cases
+    with fewer K-tiles than waves (1x1, Cin = 16: one tile, three idle waves) are part of the list."""
+    B, H, W, Cin, Cout, k = case
+    rng = np.random.default_rng(hash(case) % 2**31 + 1)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
+    mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if k == 1 else None
+    try:
+        assert be.lib.dr_dbg_force_tile(6) == 0
+        y, st = be.conv2d(x, w, scale, shift, True, res, mask, -0.5, want_stats=True)
+    finally:
+        be.lib.dr_dbg_force_tile(-1)
+    yr, raw = ref_conv2d(x, w, scale, shift, True, res, mask, -0.5)
+    assert _rel(y, yr) < 2e-5
+    np.testing.assert_allclose(st[0], raw.sum((0, 1, 2)), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(st[1], (raw ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-4)
+
+
 def test_conv_transpose_detecting(be):
     """A = identity-like input with an ASYMMETRIC weight matrix: catches a swapped MFMA C/D layout."""
     Cin = Cout = 64
@@ -75,11 +99,12 @@ def test_conv_golden_vectors(be):
         assert _rel(y, g['y%d' % i]) < 2e-5
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, 6])
 def test_conv_every_tile_shape(be, tile):
     """Each tile configuration of the implicit-GEMM kernel (the heuristic only exercises some per shape)."""
     rng = np.random.default_rng(tile)
-    np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32, 5: 64}[tile]          # 5 = 64x64 tile with the fat (BK = 64) K-tile
+    np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32, 5: 64, 6: 32}[tile]   # 5 = 64x64 tile with the fat (BK = 64) K-tile,
+                                                                             # 6 = 32x32 tile, K split over the four waves
     Cout, Cin, k = np_needed - 3, 37, 3
     x = rng.standard_normal((1, 9, 15, Cin)).astype(np.float32)          # 135 rows: ragged last M tile
     w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
@@ -119,7 +144,7 @@ def test_conv_lds_dma_refill_variant(be, monkeypatch):
         outs.append(y)
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 6])
 def test_conv_bf16_matrix_core_variant(be, tile):
     """BF kernels (v_mfma_f32_32x32x16_bf16, conv_igemm.h): both operands rounded to bf16 as they are staged, fp32
     accumulation and epilogue.  Reference = the fp64 conv of the bf16-rounded operands, so what is left is fp32
@@ -127,7 +152,7 @@ def test_conv_bf16_matrix_core_variant(be, tile):
     half slot (37, 67, 515-like 35), a short last 32-channel K-tile, a single K-tile, row mask, residual, poison in
     the padding channels."""
     rng = np.random.default_rng(100 + tile)
-    np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32}[tile]
+    np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32, 6: 96}[tile]
     Cout = np_needed - 3
     try:
         assert be.lib.dr_dbg_force_tile(tile) == 0 and be.lib.dr_dbg_force_bf16(1) == 0

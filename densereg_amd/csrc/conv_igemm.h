@@ -54,6 +54,9 @@ struct ConvParams {
     // stat_part rows hold sum(g) and sum(g*yhat), g = dOut * [raw*scale+shift > 0], yhat = (raw-mean)*inv_std, instead
     // of the forward moments.  bst_raw is the layer's raw conv output (row stride bst_cs), bst_bnc = [mean | inv_std].
     const float* bst_raw; int bst_cs; const float* bst_scale; const float* bst_shift; const float* bst_bnc; int bst_relu;
+    int Ng;                                // > 0: compute only the first Ng (multiple of 32, <= Np) output columns -- Np
+                                           // stays the row stride of the packed weights (input gradients of a concat
+                                           // buffer whose last channels have no consumer)
     int bf16;                              // w holds bf16 [Kp/32][tap][Np][32] (Kp % 32 == 0): launch the BF kernels
 };
 

@@ -51,7 +51,7 @@ namespace dr {
 template <int BM, int BN, int WM, int WN, int BK = 16, int GL = 0, int BF = 0>
 static void launch_cfg(const ConvParams& p, hipStream_t s) {
     const int M = p.B * p.H * p.W;
-    dim3 grid(dr_ceil_div(M, BM), dr_ceil_div(p.Np, BN));
+    dim3 grid(dr_ceil_div(M, BM), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, BN));
     DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF>), grid, dim3(256), 0, s, p);
 }
 
@@ -70,6 +70,7 @@ static int g_dbg_bf16 = 0;           // test/bench hook (dr_dbg_force_bf16): dr_
 int conv_tile_id(const ConvParams& p) {
     const int M = p.B * p.H * p.W;
     if (g_force_tile >= 0) return g_force_tile;
+    const int ncols = p.Ng > 0 ? p.Ng : p.Np;                 // output columns this launch computes
     // Measured on MI355X (profiles/r01_conv_microbench.md): what decides between the tiles of one N width is how
     // evenly the workgroups fall on the 256 CUs.  M = 40960 rows: Np = 256 / 512 give 1280 / 2560 64x128 workgroups
     // = 5 / 10 per CU (3x3 256->256: 99 TFLOP/s, 128-row tiles 95); Np = 128 gives 640 = 2.5 per CU, and the 64x64
@@ -82,15 +83,15 @@ int conv_tile_id(const ConvParams& p) {
     // Below ~128 such workgroups (8x8 pixels and smaller at B = 40) even that leaves most of the chip idle while each wave
     // issues the whole K axis: the split-K kernel (conv_splitk.h) quarters the chain and quadruples the workgroups
     // (profiles/r01_conv_small_layers.md: 3x3 64->64 at 8x8 18.7 -> 10.9 us, 1x1 128->64 7.5 -> 5.5 us; at 16x16 it loses).
-    if (rows64 * dr_ceil_div(p.Np, 64) <= 128 && (long)p.ksize * p.ksize * dr_ceil_div(p.Kp, p.bf16 ? 32 : 16) >= 4) return KID_CONV_SPLITK;
-    if (!p.bf16 && p.Np % 64 == 0 && rows64 * (p.Np / 64) <= 256 && (long)p.ksize * p.ksize * p.Kp >= 128) return KID_CONV_64x64_K64;
-    if (p.Np % 128 == 0) {
-        const long b128 = rows128 * (p.Np / 128), b64x128 = rows64 * (p.Np / 128), b64x64 = rows64 * (p.Np / 64);
+    if (rows64 * dr_ceil_div(ncols, 64) <= 128 && (long)p.ksize * p.ksize * dr_ceil_div(p.Kp, p.bf16 ? 32 : 16) >= 4) return KID_CONV_SPLITK;
+    if (!p.bf16 && ncols % 64 == 0 && rows64 * (ncols / 64) <= 256 && (long)p.ksize * p.ksize * p.Kp >= 128) return KID_CONV_64x64_K64;
+    if (ncols % 128 == 0) {
+        const long b128 = rows128 * (ncols / 128), b64x128 = rows64 * (ncols / 128), b64x64 = rows64 * (ncols / 64);
         if (b128 >= 4096) return KID_CONV_128x128;
         if (b64x128 < 256 || 0.92 * balance(b64x64) > balance(b64x128)) return KID_CONV_64x64;
         return KID_CONV_64x128;
     }
-    if (p.Np % 64 == 0) return (rows128 * (p.Np / 64) >= 4096) ? KID_CONV_128x64 : KID_CONV_64x64;
+    if (ncols % 64 == 0) return (rows128 * (ncols / 64) >= 4096) ? KID_CONV_128x64 : KID_CONV_64x64;
     return KID_CONV_128x32;
 }
 
@@ -103,14 +104,14 @@ int conv_stat_rows(const ConvParams& p) {
 }
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
-    if (p.x_cs % 4 || p.x_coff % 4 || p.Kp % 16 || p.Np % 32 || !p.zeros) return -1;
+    if (p.x_cs % 4 || p.x_coff % 4 || p.Kp % 16 || p.Np % 32 || !p.zeros || p.Ng % 32 || p.Ng > p.Np) return -1;
     // the kernel addresses every tensor with 32-bit element offsets from its base pointer
     const long long M = (long long)p.B * p.H * p.W;
     const long long widest = std::max(std::max((long long)p.x_cs, (long long)p.y_cs), std::max((long long)p.res_cs, (long long)p.Cout));
     if (M * widest >= (1ll << 32)) return -1;
     if (conv_tile_id(p) == KID_CONV_SPLITK) {
         if (p.bf16 && p.Kp % 32) return -1;
-        dim3 grid(dr_ceil_div((int)M, 32), dr_ceil_div(p.Np, 32));
+        dim3 grid(dr_ceil_div((int)M, 32), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, 32));
         if (p.bf16) DR_LAUNCH((conv_splitk_kernel<1>), grid, dim3(256), 0, s, p);
         else DR_LAUNCH((conv_splitk_kernel<0>), grid, dim3(256), 0, s, p);
         return 0;
@@ -481,7 +482,7 @@ static void free_all(dr_handle* h) {
     for (void* p : {(void*)h->flat_param, (void*)h->flat_grad, (void*)h->adam_m, (void*)h->adam_v, (void*)h->flat_state, (void*)h->flat_state_next,
                     (void*)h->shadow, (void*)h->wp, (void*)h->wpT, (void*)h->fold, (void*)h->stats, (void*)h->bnc,
                     (void*)h->act_arena, (void*)h->grad_arena, (void*)h->scratch, (void*)h->tiny, (void*)h->tiny_ext, (void*)h->zeros,
-                    (void*)h->losses, (void*)h->reg_segs, (void*)h->loss_acc, (void*)h->bn_coef, (void*)h->wg_partial, (void*)h->fold_dev, h->pack_dev})
+                    (void*)h->losses, (void*)h->reg_segs, (void*)h->loss_acc, (void*)h->bn_coef, (void*)h->wg_partial, (void*)h->fold_dev, h->pack_dev, h->zero_dev})
         if (p) rt::dfree(p);
     for (int l = 1; l < DR_MAX_LANES; ++l) {
         if (h->scratch_l[l]) rt::dfree(h->scratch_l[l]);

@@ -18,6 +18,8 @@ struct Tensor {
     float* g = nullptr;                // gradient buffer (training handles)
     bool needs_grad = true;
     bool needs_zero = false;           // gradient buffer must be zeroed before a backward pass (see plan_backward)
+    int grad_C = 0;                    // channels [0, grad_C) of the gradient have a consumer (plan_backward): the tail of a
+                                       // concat buffer written by an op without a backward (the uvd planes) needs no dgrad
     std::string tag;
 };
 
@@ -170,6 +172,7 @@ struct dr_handle {
     float* wg_partial_l[dr::DR_MAX_LANES] = {};             // one per lane (index 0 aliases `wg_partial`)
     // deferred slab fold (single-stream executor): every layer keeps its slabs until one fold launch at the end
     std::vector<dr::FoldSeg> fold_host;                     // segments of the sweep in progress
+    void* zero_dev = nullptr; int zero_nseg = 0;            // ZeroSeg table of the gradient buffers dr_loss clears (plan_backward)
     dr::FoldSeg* fold_dev = nullptr;                        // device copy (capacity = number of convs)
     std::vector<dr::FoldSeg> fold_uploaded;                 // what fold_dev currently holds (re-uploaded only on change)
     size_t fold_head = 0;                                  // floats at the start of wg_partial kept for immediate folds

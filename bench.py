@@ -102,6 +102,11 @@ def pmc_traffic(mode, kernel):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: anything else written to file descriptor 1 during the run (RCCL prints a
+    # version banner there from C when the first communicator is created) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -228,7 +233,7 @@ def main():
                        'conv_gflop_per_crop_fwd': eng.conv_flops_per_crop() / 1e9},
             'roofline': roof, 'cpu_baseline': cpu,
         }
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.destroy_process_group()
 

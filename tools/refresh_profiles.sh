@@ -15,6 +15,10 @@ cp $G/bench_train.json profiles/${R}_bench_train.json
 cp $G/bench_infer.json profiles/${R}_bench_infer.json
 cp $G/detail_train.md profiles/${R}_train_per_layer.md
 cp $G/detail_infer.md profiles/${R}_infer_per_layer.md
+for p in bf16; do
+  [ -f $G/bench_infer_$p.json ] && cp $G/bench_infer_$p.json profiles/${R}_bench_infer_$p.json && cp $G/detail_infer_$p.md profiles/${R}_infer_per_layer_$p.md
+  [ -f $G/bench_train_$p.json ] && cp $G/bench_train_$p.json profiles/${R}_bench_train_$p.json && cp $G/detail_train_$p.md profiles/${R}_train_per_layer_$p.md
+done
 [ -f $G/conv_bench.md ] && cp $G/conv_bench.md profiles/${R}_conv_microbench.md
 [ -f $G/conv_counters.md ] && cp $G/conv_counters.md profiles/${R}_conv_sq_counters.md
 echo refreshed profiles/${R}_*

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# Turn the scratch output of tools/gpu_run4.sh (gpurun_out/) into the tracked summaries under profiles/.
+# Turn the scratch output of tools/gpu/full_visit.sh (gpurun_out/) into the tracked summaries under profiles/.
 #   tools/refresh_profiles.sh r01
 set -e
 R=${1:-r01}

@@ -100,6 +100,37 @@ def test_train_step_single_stack(be):
     h.close()
 
 
+def test_train_step_input_256(be):
+    """BASELINE config 5's geometry in training: 256x256 crops, hourglass depth 5, 64x64 maps (um_v1.py:99-104) -- one
+    micro-step of a narrow network (S=1, F=16, J=3) against the oracle: losses and every gradient."""
+    import torch
+    from densereg_amd.data.synthetic import make_crops
+    from oracle import net, pose, train
+    from oracle.graph import NetConfig
+    cfg = NetConfig(1, 16, 3, in_hw=256)
+    dm, poses, cfgs, coms, _ = make_crops(1, 'nyu', seed=3, hw=256)
+    poses = np.ascontiguousarray(poses[:, :9])
+    ndm = pose.norm_dm(dm, coms)
+    params = net.make_test_params(cfg, ndm, seed=7)
+    h = be.handle(cfg, 1, training=True)
+    h.load_params(params)
+    h.call('dr_finalize_params', be.stream)
+    d_dm, d_pose, d_cfg, d_com, d_lo = be.dev(ndm), be.dev(poses), be.dev(cfgs), be.dev(coms), be.empty((4,))
+    h.call('dr_forward_train', 1, be.ptr(d_dm), 0, None, C.c_uint64(0), be.stream)
+    h.call('dr_loss', 1, be.ptr(d_dm), be.ptr(d_pose), be.ptr(d_cfg), be.ptr(d_com), be.ptr(d_lo), be.stream)
+    h.call('dr_zero_grad', be.stream)
+    h.call('dr_backward', 1, be.stream)
+    be.sync()
+    g = flat_grads_by_name(be, h, cfg)
+    lo32, g32, _, _ = train.loss_and_grads(cfg, params, ndm, poses, cfgs, coms)
+    _, g64, _, _ = train.loss_and_grads(cfg, params, ndm, poses, cfgs, coms, dtype=torch.float64)
+    np.testing.assert_allclose(be.host(d_lo), [lo32[k] for k in ('hm', 'hm3', 'um', 'reg')], rtol=2e-4)
+    e_eng = np.array([np.abs(g[n] - g64[n]).max() / (np.abs(g64[n]).max() + 1e-12) for n in g64])
+    e_o32 = np.array([np.abs(g32[n] - g64[n]).max() / (np.abs(g64[n]).max() + 1e-12) for n in g64])
+    assert e_eng.max() < 6e-2 and np.median(e_eng) < 2 * np.median(e_o32) + 1e-4, (e_eng.max(), np.median(e_eng), np.median(e_o32))
+    h.close()
+
+
 def test_train_step_bf16_precision(be):
     """dr_set_precision(DR_PREC_BF16) on a training handle: forward, input-gradient and weight-gradient convolutions
     all round their two operands to bf16 on the way into the matrix cores (fp32 accumulation, fp32 tensors, fp32

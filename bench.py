@@ -44,6 +44,12 @@ def parse():
     ap.add_argument('--mode', choices=['train', 'infer'], default=os.environ.get('DR_BENCH_MODE', 'train'))
     ap.add_argument('--batch', type=int, default=40)
     ap.add_argument('--sub_batch', type=int, default=5)
+    # the headline workload is the default; the other BASELINE configs (e.g. config 5: --num_stack 4 --num_fea 256 --in_hw 256
+    # --dataset nyu --precision bf16) are reachable for measurement and say so in `metric` / `config.workload`
+    ap.add_argument('--num_stack', type=int, default=2)
+    ap.add_argument('--num_fea', type=int, default=128)
+    ap.add_argument('--in_hw', type=int, default=128, choices=[128, 256, 512])
+    ap.add_argument('--dataset', default='', choices=['', 'icvl', 'nyu', 'msra'], help='default: nyu for train, icvl for infer')
     ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
                     help='matrix-core arithmetic of the convolutions; bf16 = BASELINE config 5\'s conv path (fp32 stays the headline)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -125,10 +131,10 @@ def main():
     from densereg_amd.parallel import DataParallelTrainer
 
     mode = args.mode
-    dataset = 'nyu' if mode == 'train' else 'icvl'
+    dataset = args.dataset or ('nyu' if mode == 'train' else 'icvl')
     J = DATASETS[dataset]['jnt_num']
-    S, F, B = 2, 128, args.batch
-    eng = Engine(S, F, J, 128, 3, B, local, training=(mode == 'train'))
+    S, F, B, HW = args.num_stack, args.num_fea, args.batch, args.in_hw
+    eng = Engine(S, F, J, HW, 3, B, local, training=(mode == 'train'))
     bf16 = args.precision == 'bf16'
     if bf16:
         eng.set_precision('bf16')
@@ -147,7 +153,7 @@ def main():
             params[name] = np.zeros(shape, np.float32)
     eng.load_params(params)
 
-    dm, poses, cfgs, coms, _ = make_crops(B, dataset, seed=20240, rank=rank)
+    dm, poses, cfgs, coms, _ = make_crops(B, dataset, seed=20240, rank=rank, hw=HW)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     d_dm_mm, d_pose, d_cfg, d_com = t(dm), t(poses), t(cfgs), t(coms)
     d_dm = eng.norm_dm(d_dm_mm, d_com)
@@ -216,16 +222,16 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(mode, (S, F, J), B, dataset)
+        cpu = cpu_baseline(mode, (S, F, J), B, dataset) if HW == 128 else None
 
     if rank == 0:
         crops = B * world * args.steps
         out = {
-            'metric': 'depth-crops/sec %s, 2-stack fea=128 @128x128' % ('fwd+bwd' if mode == 'train' else 'fwd(eval)+vote'),
+            'metric': 'depth-crops/sec %s, %d-stack fea=%d @%dx%d' % ('fwd+bwd' if mode == 'train' else 'fwd(eval)+vote', S, F, HW, HW),
             'value': crops / dt, 'unit': 'crops/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
-            'config': {'workload': ('%s S=2 F=128 J=%d B=%d/GPU 128x128 ' % (dataset.upper(), J, B)) +
+            'config': {'workload': ('%s S=%d F=%d J=%d B=%d/GPU %dx%d ' % (dataset.upper(), S, F, J, B, HW, HW)) +
                        ('train micro-step fwd+loss+bwd, RCCL all-reduce + clip + Adam every %d steps' % args.sub_batch
                         if mode == 'train' else 'forward(eval) + vote -> xyz mm') +
                        (', bf16 matrix cores on fp32 tensors (fp32 accumulate, epilogues, vote)' if bf16 else ''),

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256, 2) void conv_splitk_kernel(const ConvParams p)
     slot_setup(0, a_off0, a_taps0);
     slot_setup(1, a_off1, a_taps1);
     const bool ragged = (p.Cin & 3) != 0;
-    float4 a_reg0, a_reg1, a_hi0, a_hi1, b_reg0, b_reg1;
+    float4 a_reg0, a_reg1, b_reg0, b_reg1;
+    float4 a_hi0 = make_float4(0.f, 0.f, 0.f, 0.f), a_hi1 = a_hi0;         // channels 4..7 of a slot: bf16 operands only
     int a_nv0 = CS, a_nv1 = CS;
     auto load_one = [&](const int i, const int kc, const int tap, const float* ld_x, const float* ld_w, const unsigned off,
                         const unsigned tapmask, float4& areg, float4& ahi, float4& breg, int& anv) __attribute__((always_inline)) {

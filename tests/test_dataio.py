@@ -90,6 +90,28 @@ def test_oracle_example_wire_format_known_answer():
     np.testing.assert_array_equal(tfrecord.parse_example(b'\x0a' + bytes([len(features)]) + features)['b'], [3.0, 4.0])
 
 
+def test_committed_fixtures_pillow_png_and_record_shard(tmp_path):
+    """tests/golden/dataio_fixtures.npz (made by tests/golden/make_dataio_fixtures.py): PNG streams written by Pillow and
+    the sample arrays they hold; a TFRecord shard with two records.  Engine decoder and oracle agree with the data."""
+    from tests.common import golden
+    g = golden('dataio_fixtures.npz')
+    for key, ref, ch, depth in (('png_grey16', g['depth16'], 1, 16), ('png_grey16_opt', g['depth16'], 1, 16), ('png_rgb8', g['rgb'], 3, 8)):
+        blob = g[key].tobytes()
+        info, s = png.decode_png(blob)
+        assert (info.width, info.height, info.channels, info.bit_depth) == (40, 24, ch, depth)
+        np.testing.assert_array_equal(s, oracle_io.png_decode(blob)[4])
+        np.testing.assert_array_equal(oracle_io.depth_from_samples(s, ch, depth), g['depth16'].astype(np.float32))
+        if ch == 3:
+            np.testing.assert_array_equal(s.reshape(24, 40, 3), ref)
+    path = str(tmp_path / 'shard')
+    open(path, 'wb').write(g['shard'].tobytes())
+    recs = list(tfrecord.read_records(path))
+    assert len(recs) == 2 and recs[1] == b'second' and oracle_io.records(g['shard'].tobytes()) == recs
+    f = tfrecord.parse_example(recs[0])
+    assert f['name'] == [b'test_seq_1/image_0000.png'] and f['png16'][0] == g['png_grey16'].tobytes()
+    np.testing.assert_array_equal(f['xyz_pose'], g['pose'])
+
+
 # ---------------------------------------------------------------------------------------------
 # host pieces of the engine
 # ---------------------------------------------------------------------------------------------

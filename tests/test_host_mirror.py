@@ -19,6 +19,13 @@ def test_flags_match_reference_names_and_defaults():
     assert F.num_fea == 64 and F.num_stack == 1 and F.is_train is False and F.dataset == 'icvl'      # README spelling accepted
     F = flags.parse(['--num_fea', '256', '--is_train', 'True'])
     assert F.num_fea == 256 and F.is_train is True
+    # this build's additions keep the reference's behaviour by default
+    F = flags.parse([])
+    assert (F.precision, F.data_dir, F.restore_step, F.save_every) == ('f32', '', 0, 0)
+    F = flags.parse(['--precision', 'bf16', '--data_dir', '/data/nyu'])
+    assert F.precision == 'bf16' and F.data_dir == '/data/nyu'
+    with pytest.raises(SystemExit):
+        flags.parse(['--precision', 'fp8'])
     flags.parse([])
 
 

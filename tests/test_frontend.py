@@ -173,6 +173,33 @@ def test_crop_from_bbx_and_center_of_mass_identity(be):
         np.testing.assert_allclose(com[b], F.center_of_mass(sq[b], cf[b]), rtol=2e-6)
 
 
+def test_crop_from_bbx_on_the_reference_nyu_boxes(be):
+    """tests/golden/nyu_bbx_head.npy = the first 16 rows of the reference's data/nyu_bbx.pkl (data, not code): they pin the
+    (top, left, bottom, right, depth threshold) convention of crop_from_bbx (data/preprocess.py:81-129; call site
+    data/nyu.py:209-214) -- boxes inside the 480x640 NYU frame, thresholds in the sensor's range -- and are the boxes
+    this test crops with: engine vs oracle on synthetic NYU-sized frames."""
+    import os
+    from tests.common import GOLDEN
+    bbx = np.load(os.path.join(GOLDEN, 'nyu_bbx_head.npy'))
+    assert bbx.shape == (16, 5) and bbx.dtype == np.float32
+    top, left, bottom, right, d_th = bbx.T
+    assert (top >= 0).all() and (left >= 0).all() and (bottom > top).all() and (right > left).all()
+    assert (bottom <= 480).all() and (right <= 640).all() and ((d_th > 500) & (d_th < 1500)).all()
+    B = 4 if be.name == 'emu' else 16
+    rng = np.random.default_rng(12)
+    H, W = 480, 640
+    dms = rng.uniform(600, 1400, (B, H, W)).astype(np.float32)
+    dms[rng.uniform(size=dms.shape) < 0.1] = 0.0
+    cfgs = np.tile(np.array([588.235, 587.084, 320.0, 240.0, W, H], np.float32), (B, 1))
+    crops, ncfg, com = _crop_abi(be, dms, None, cfgs, False, out_hw=128, bbx=np.ascontiguousarray(bbx[:B]))
+    for b in range(B):
+        rc, _, rcfg = F.crop_from_bbx(dms[b], None, bbx[b], cfgs[b], 128, 128)
+        np.testing.assert_allclose(ncfg[b], rcfg, rtol=1e-6)
+        assert np.abs(crops[b] - rc).max() < 2e-3
+        assert (crops[b] < d_th[b]).all()                           # the box's own threshold removed the background
+        np.testing.assert_allclose(com[b], F.center_of_mass(rc, rcfg), rtol=2e-6, atol=1e-4)
+
+
 def _aug_abi(be, dms, poses, cfgs, coms, draws):
     B, H, W = dms.shape
     args = [be.dev(np.ascontiguousarray(a, np.float32)) for a in (dms, poses, cfgs, coms, draws)]

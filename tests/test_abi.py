@@ -5,6 +5,8 @@ import os
 import re
 import subprocess
 
+import pytest
+
 from tests.common import ROOT
 
 from densereg_amd import _lib
@@ -66,3 +68,27 @@ def test_package_does_not_import_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), os.path.join(dirpath, f)
                 assert 'hipemu' not in src and 'libdensereg_emu' not in src, os.path.join(dirpath, f)
+
+
+def test_headers_are_c99_and_a_c_program_links_against_the_library(tmp_path):
+    """include/*.h is a C ABI: it compiles as pedantic C99, and examples/abi_probe.c (host-side entry points only:
+    no GPU needed) builds with gcc against libdensereg_hip.so and gets the right answers."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc in this environment')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc, libdir = os.path.join(root, 'include'), os.path.join(root, 'densereg_amd', 'lib')
+    both = tmp_path / 'both.c'
+    both.write_text('#include "densereg.h"\n#include "densereg_debug.h"\nint main(void) { return 0; }\n')
+    r = subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', inc, '-fsyntax-only', str(both)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = str(tmp_path / 'abi_probe')
+    r = subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-I', inc, os.path.join(root, 'examples', 'abi_probe.c'), '-o', exe,
+                        '-L', libdir, '-ldensereg_hip', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert 'backend=hip-gfx950' in r.stdout and 'crc32c=e3069283' in r.stdout and 'unfilter_ok=1' in r.stdout

@@ -42,7 +42,8 @@ def build_parser() -> argparse.ArgumentParser:
                    help='matrix-core arithmetic of the convolutions (dr_set_precision); the reference is fp32')
     p.add_argument('--data_dir', default='', help='dataset root holding the TFRecord shards (exp/data/<dataset>/ in the reference); '
                    'empty = seeded synthetic crops')
-    p.add_argument('--restore_step', type=int, default=0, help='restore <train_dir>/model.ckpt-<step> (TF V2 checkpoint) before training / testing')
+    p.add_argument('--restore_step', type=int, default=0, help='restore <train_dir>/model.ckpt-<step> (TF V2 checkpoint) before training / testing; 0 = none when training, '
+                   'model.ckpt--1 if present when testing (the reference tests with step -1)')
     p.add_argument('--save_every', type=int, default=0, help='train: write <train_dir>/model.ckpt-<step> every N optimizer steps and at the end (0 = never)')
     return p
 

@@ -169,12 +169,26 @@ def train(model: JointDetectionModel, dist=None, log=sys.stdout):
     return trainer
 
 
+def checkpoint_for_test(train_dir: str, restore_step: int):
+    """Which checkpoint a test run restores.  The reference always restores step -1 (``run_test(dataset, val_dataset, -1)``,
+    ``…tiny.py:908`` -> ``model.ckpt--1``, the name of the published models, ``exp/scripts/fetch_*_model.sh``); here
+    ``--restore_step N`` (N != 0) names a step explicitly and must exist, and without it ``model.ckpt--1`` is restored when
+    present -- otherwise the run keeps its random weights (no checkpoint can exist in this environment)."""
+    if restore_step != 0:
+        return os.path.join(train_dir, 'model.ckpt-%d' % restore_step)
+    default = os.path.join(train_dir, 'model.ckpt--1')
+    return default if os.path.exists(default + '.index') else None
+
+
 def test_model(model: JointDetectionModel, out_path: str, log=sys.stdout):
     """test_model.test (:14-94): run the test set, write one result line per frame, return the errors."""
     F = flags.FLAGS
     total = F.num_frames or model._val_dataset.exact_num
-    if F.restore_step > 0:                                                  # test_model.py:33-34
-        model.engine.load_checkpoint(os.path.join(model.train_dir, 'model.ckpt-%d' % F.restore_step), strict=True)
+    ckpt = checkpoint_for_test(model.train_dir, F.restore_step)             # test_model.py:31-35
+    if ckpt is not None:
+        model.engine.load_checkpoint(ckpt, strict=True)
+        if log:
+            print('[test_model]model has been restored from %s' % ckpt, file=log)
     max_err, mean_err, n, step = [], [], 0, 0
     with open(out_path, 'w') as f:
         while n < total:

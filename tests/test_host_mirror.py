@@ -29,6 +29,16 @@ def test_flags_match_reference_names_and_defaults():
     flags.parse([])
 
 
+def test_checkpoint_a_test_run_restores(tmp_path):
+    from densereg_amd.model.hourglass_um_crop_tiny import checkpoint_for_test
+    d = str(tmp_path)
+    assert checkpoint_for_test(d, 0) is None                                   # nothing published here: random weights
+    open(os.path.join(d, 'model.ckpt--1.index'), 'wb').close()
+    assert checkpoint_for_test(d, 0) == os.path.join(d, 'model.ckpt--1')      # the reference's run_test(…, -1)
+    assert checkpoint_for_test(d, 1500) == os.path.join(d, 'model.ckpt-1500')  # explicit step
+    assert checkpoint_for_test(d, -1) == os.path.join(d, 'model.ckpt--1')
+
+
 def test_result_line_format_matches_shipped_prediction_files():
     """exp/result/icvl.txt / nyu.txt pin the output FORMAT: name, tab, %.4f fields, '\\' separators."""
     from densereg_amd.model.hourglass_um_crop_tiny import result_line

@@ -83,8 +83,7 @@ def decode_png(data: bytes):
     from .. import _lib
     info, raw = inflate_png(data)
     out = np.empty((info.height, info.row_bytes), np.uint8)
-    src = (C.c_char * len(raw)).from_buffer_copy(raw)
-    rc = _lib.load().dr_png_unfilter(src, info.height, info.row_bytes, info.bpp, out.ctypes.data)
+    rc = _lib.load().dr_png_unfilter(raw, info.height, info.row_bytes, info.bpp, out.ctypes.data)   # bytes: passed by pointer, no copy
     if rc != 0:
         raise PngError('dr_png_unfilter failed (%d): unknown filter type' % rc)
     return info, out

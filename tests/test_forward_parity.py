@@ -178,6 +178,36 @@ def test_conv_bf16_matrix_core_variant(be, tile):
         be.lib.dr_dbg_force_bf16(0)
 
 
+def test_bf16_operand_rounding_is_nearest_even(be):
+    """The staging path rounds activations with v_cvt_pk_bf16_f32 (the emulator: clang's float -> __bf16), the packing
+    kernel rounds weights the same way: round to nearest, ties to even.  Exact ties (a 1 in mantissa bit 15, zeros
+    below) through an identity 1x1 conv come out as the even neighbour, bit for bit; so do values just above / below a
+    tie, negative numbers, and the weight side (a diagonal of tie values against a one-hot input)."""
+    C_ = 32
+    k = np.arange(C_, dtype=np.uint32)
+    bits = (np.uint32(0x3F800000) | (k << np.uint32(16)) | np.uint32(0x8000))           # 1.xxxxxxx | tie bit
+    ties = bits.view(np.float32)
+    above = (bits + np.uint32(1)).view(np.float32)                                       # must round up
+    below = (bits - np.uint32(1)).view(np.float32)                                       # must round down
+    x = np.stack([ties, -ties, above, below]).reshape(1, 2, 2, C_).astype(np.float32)
+    eye = np.eye(C_, dtype=np.float32).reshape(1, 1, C_, C_)
+    expect_even = ((bits + np.uint32(0x7FFF) + ((bits >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    np.testing.assert_array_equal(bf16_round(ties), expect_even)                         # the reference rounding itself
+    try:
+        assert be.lib.dr_dbg_force_bf16(1) == 0
+        for tile in (1, 3, 6):
+            assert be.lib.dr_dbg_force_tile(tile) == 0
+            y = be.conv2d(x, eye)
+            np.testing.assert_array_equal(y.reshape(4, C_), bf16_round(x).reshape(4, C_))
+            # weights: diag(ties) against ones -> the rounded diagonal
+            w = (np.eye(C_, dtype=np.float32) * ties[None, :]).reshape(1, 1, C_, C_)
+            yw = be.conv2d(np.ones((1, 1, 1, C_), np.float32), w)
+            np.testing.assert_array_equal(yw.reshape(C_), expect_even)
+    finally:
+        be.lib.dr_dbg_force_tile(-1)
+        be.lib.dr_dbg_force_bf16(0)
+
+
 def test_conv_plain_linear(be):
     rng = np.random.default_rng(5)
     x = rng.standard_normal((2, 5, 5, 24)).astype(np.float32)

@@ -115,7 +115,9 @@ def main():
     os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    # one rank per GPU; if the launcher narrows device visibility to one GPU per process, that GPU is index 0
+    local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)                        # before the process group: RCCL binds to the current device
     dist = None
     if world > 1 or os.environ.get('DR_FORCE_ALLREDUCE') == '1':
         import torch.distributed as dist
@@ -123,7 +125,6 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world)
     assert world == args.gpus or world == 1, 'launch N>1 through torch.distributed.run'
-    torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
     from densereg_amd import _lib

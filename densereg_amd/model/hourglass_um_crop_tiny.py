@@ -246,7 +246,7 @@ def main(argv=None):
     F = flags.parse(argv)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -8,7 +8,8 @@ the device) -> ``dr_crop_from_pose`` / ``dr_crop_from_bbx`` (crop, resize, thres
 ``preprocess_op`` of the reference) -> ``[dm (B,128,128,1), pose (B,3J), cfg (B,6), com (B,3), names]``, the tuple
 ``JointDetectionModel.loss`` / ``.test`` consume.  The queue-runner machinery of the reference (shuffle queues,
 reader threads: ``dataset_base.py:153-205``) is replaced by a shard-level and buffer-level shuffle with a seeded
-generator; ranks of a data-parallel job read disjoint shards.
+generator, a decode thread pool and a producer thread that keeps two decoded batches ahead of the GPU
+(``host_batches``); ranks of a data-parallel job read disjoint shards.
 
 Where the reference is ambiguous this file says what it does:
 * ``IcvlDataset.is_train`` returns True for every subset (``icvl.py:46-47``), so its ``loadAnnotation`` would drop
@@ -177,18 +178,80 @@ class BaseDataset(object):
         from . import preprocess
         return preprocess.crop_and_com_from_pose(frames, poses, cfgs, out_hw, out_hw, dataset=self.name)
 
+    def host_batches(self, batch_size: int, shuffle: bool, seed: int = 0, rank: int = 0, world: int = 1,
+                     epochs: Optional[int] = None, drop_last: bool = False, files: Optional[Sequence[str]] = None,
+                     workers: int = 4, prefetch: int = 2) -> Iterator[list]:
+        """The host half of the pipeline: lists of ``parse_example`` results, one list per batch, in stream order.
+
+        ``workers`` threads decode the frames of a batch concurrently (zlib and ``dr_png_unfilter`` release the GIL; one
+        thread decodes ~2600 ICVL or ~500 NYU frames/s, the training step consumes ~1800 crops/s:
+        ``profiles/r01_dataio_bench.md``) -- the reference's ``num_preprocess_threads``.  With ``prefetch`` > 0 a
+        producer thread stays that many decoded batches ahead of the consumer, so decoding overlaps the GPU step the way
+        the reference's queue runners did (``dataset_base.py:153-205``); an exception in the producer is re-raised at the
+        consumer's next ``next()``."""
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+
+        def produce() -> Iterator[list]:
+            pool = ThreadPoolExecutor(workers) if workers > 1 else None
+            try:
+                pend: List[bytes] = []
+                for rec in self.records(shuffle, seed, rank, world, epochs, files):
+                    pend.append(rec)
+                    if len(pend) == batch_size:
+                        yield list(pool.map(self.parse_example, pend)) if pool else [self.parse_example(r) for r in pend]
+                        pend = []
+                if pend and not drop_last:
+                    yield list(pool.map(self.parse_example, pend)) if pool else [self.parse_example(r) for r in pend]
+            finally:
+                if pool:
+                    pool.shutdown(wait=False)
+
+        if prefetch <= 0:
+            yield from produce()
+            return
+        q: 'queue.Queue' = queue.Queue(maxsize=prefetch)
+        stop = threading.Event()
+        END = object()
+
+        def run():
+            try:
+                for items in produce():
+                    while not stop.is_set():
+                        try:
+                            q.put(items, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+                q.put(END)
+            except BaseException as e:                                        # handed to the consumer
+                q.put(e)
+
+        th = threading.Thread(target=run, name='%s-decode' % self.name, daemon=True)
+        th.start()
+        try:
+            while True:
+                items = q.get()
+                if items is END:
+                    return
+                if isinstance(items, BaseException):
+                    raise items
+                yield items
+        finally:                                                              # consumer stopped early: let the producer exit
+            stop.set()
+
     def batches(self, batch_size: int, device, out_hw: int = 128, shuffle: Optional[bool] = None, seed: int = 0, rank: int = 0,
                 world: int = 1, epochs: Optional[int] = None, drop_last: bool = False, files: Optional[Sequence[str]] = None,
-                workers: int = 4):
-        """``workers`` host threads decode the frames of a batch concurrently (zlib and ``dr_png_unfilter`` release the
-        GIL; one thread decodes ~2600 ICVL or ~500 NYU frames/s, the training step consumes ~1700 crops/s:
-        ``profiles/r01_dataio_bench.md``) -- the reference's ``num_preprocess_threads``."""
+                workers: int = 4, prefetch: int = 2):
+        """``host_batches`` + the device half: the samples go up as bytes, ``dr_depth_from_samples`` and the crop kernel
+        produce ``[dm (B,out,out,1), pose (B,3J) (host), cfg (B,6), com (B,3), names]``."""
         import torch
         shuffle = self.is_train if shuffle is None else shuffle
-        pend = []
         cfg_row = np.asarray(self.cfg, np.float32)
-
-        def flush(items):
+        for items in self.host_batches(batch_size, shuffle, seed, rank, world, epochs, drop_last, files, workers, prefetch):
             info = items[0][0]
             samples = torch.from_numpy(np.stack([it[1] for it in items])).to(device)     # bytes go up, not floats
             frames = png.depth_from_samples(samples, info)
@@ -197,23 +260,7 @@ class BaseDataset(object):
             d_cfg = torch.from_numpy(np.tile(cfg_row, (len(items), 1))).to(device)
             bbxs = None if items[0][4] is None else torch.from_numpy(np.stack([it[4] for it in items])).to(device)
             crops, _, new_cfgs, coms = self.preprocess(frames, d_pose, d_cfg, bbxs, out_hw)
-            return crops.unsqueeze(-1), poses, new_cfgs, coms, [it[3] for it in items]
-
-        pool = None
-        if workers > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            pool = ThreadPoolExecutor(workers)
-        try:
-            for rec in self.records(shuffle, seed, rank, world, epochs, files):
-                pend.append(rec)
-                if len(pend) == batch_size:
-                    yield flush(list(pool.map(self.parse_example, pend)) if pool else [self.parse_example(r) for r in pend])
-                    pend = []
-            if pend and not drop_last:
-                yield flush(list(pool.map(self.parse_example, pend)) if pool else [self.parse_example(r) for r in pend])
-        finally:
-            if pool:
-                pool.shutdown(wait=False)
+            yield crops.unsqueeze(-1), poses, new_cfgs, coms, [it[3] for it in items]
 
     def batch(self, batch_size: int, index: int, device=None):
         """The drivers' interface (``SyntheticDataset.batch``): the next batch of an endless (training) or single-pass,

@@ -247,6 +247,19 @@ def test_icvl_adapter_annotations_shards_and_parse(tmp_path):
     assert len(r0) + len(r1) == 7 and not set(r0) & set(r1)
     with pytest.raises(ValueError):
         datasets.IcvlDataset('nonsense', root)
+    # the host half of the batch pipeline: prefetching producer thread and decode pool give the stream of the plain loop
+    plain = [[it[3] for it in b] for b in ds.host_batches(3, False, epochs=1, files=paths, workers=1, prefetch=0)]
+    ahead = [[it[3] for it in b] for b in ds.host_batches(3, False, epochs=1, files=paths, workers=4, prefetch=2)]
+    assert plain == ahead and [len(b) for b in plain] == [3, 3, 1] and sum(plain, []) == [a.name for a in ann]
+    assert [len(b) for b in ds.host_batches(3, False, epochs=1, files=paths, drop_last=True)] == [3, 3]
+    it = ds.host_batches(2, True, seed=1, epochs=None, files=paths)            # endless stream, abandoned early: no hang
+    assert len(next(it)) == 2 and len(next(it)) == 2
+    it.close()
+    blob = bytearray(open(paths[1], 'rb').read()); blob[40] ^= 0xFF
+    bad = str(tmp_path / 'corrupt-shard')
+    open(bad, 'wb').write(bytes(blob))
+    with pytest.raises(tfrecord.RecordError):                                   # a producer-side error reaches the consumer
+        list(ds.host_batches(2, False, epochs=1, files=[paths[0], bad]))
 
 
 def test_msra_bin_reader_and_label_signs(tmp_path):

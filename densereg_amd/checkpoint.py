@@ -481,7 +481,9 @@ def export_from(handle, prefix: str, global_step: Optional[int] = None, with_slo
                     scope = name.rsplit('/', 1)[0]
                     tensors['%s/%s%s' % (scope, name, suf)] = buf.reshape(shape) if suf == '/biased' else buf.reshape(())
     if global_step is not None:
-        tensors['global_step'] = np.array(global_step, np.int32)
+        # a FLOAT variable in the reference: tf.get_variable('global_step', [], initializer=constant_initializer(0)) has the
+        # default dtype float32 (train_single_gpu.py:42), and Saver.restore checks dtypes
+        tensors['global_step'] = np.array(global_step, np.float32)
     tensors.update(extra or {})
     write_checkpoint(prefix, tensors)
     return sorted(tensors)

@@ -61,8 +61,13 @@ __global__ __launch_bounds__(256) void crop_com_kernel(const CropParams p) {
             top = (int)t; left = (int)l; bottom = (int)bt; right = (int)r;
             d_th = p.icvl ? 500.f : (dmin == 3.402823466e38f ? dmin : dmin + 250.f);
         }
-        const int h = bottom - top, w = right - left;
-        const int longer = h > w ? h : w;
+        // A box is data (dataset records, nyu_bbx.pkl): the reference's crop_to_bounding_box raises on a box that leaves
+        // the frame or has no area.  Here pixels outside the frame read as background (0, like the square's zero padding,
+        // see sq below) and a degenerate box is treated as one pixel wide, so the crop camera stays finite.
+        int h = bottom - top, w = right - left;
+        h = h < 0 ? 0 : h; w = w < 0 ? 0 : w;
+        int longer = h > w ? h : w;
+        longer = longer < 1 ? 1 : longer;
         const int off_h = (int)((double)(longer - h) / 2.0), off_w = (int)((double)(longer - w) / 2.0);
         s_box[0] = top; s_box[1] = left; s_box[2] = h; s_box[3] = w; s_box[4] = longer; s_box[5] = off_h; s_box[6] = off_w;
         s_dth = d_th;
@@ -82,7 +87,9 @@ __global__ __launch_bounds__(256) void crop_com_kernel(const CropParams p) {
     auto sq = [&](int y, int x) -> float {
         const int cy = y - off_h, cx = x - off_w;
         if (cy < 0 || cy >= bh || cx < 0 || cx >= bw) return 0.f;
-        return dm[(long)(top + cy) * p.W + (left + cx)];
+        const int fy = top + cy, fx = left + cx;
+        if (fy < 0 || fy >= p.H || fx < 0 || fx >= p.W) return 0.f;          // box beyond the frame: background
+        return dm[(long)fy * p.W + fx];
     };
     double sum = 0.0;
     int cnt = 0;

@@ -178,6 +178,10 @@ class Engine:
             for name, (off, n) in self._trainable_offsets().items():
                 extra[name + '/Adam'] = m[off:off + n].reshape(shapes[name])
                 extra[name + '/Adam_1'] = v[off:off + n].reshape(shapes[name])
+            # AdamOptimizer's non-slot variables: Saver(tf.global_variables()).restore needs them.  After t applied updates
+            # they hold beta^(t+1) (TF initialises them to beta and multiplies once per apply_gradients).
+            if beta_powers is None and global_step is not None:
+                beta_powers = (0.5 ** (int(global_step) + 1), 0.999 ** (int(global_step) + 1))
             if beta_powers is not None:
                 extra['beta1_power'] = np.array(beta_powers[0], np.float32)
                 extra['beta2_power'] = np.array(beta_powers[1], np.float32)

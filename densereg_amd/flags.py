@@ -35,6 +35,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--num_fea', '--fea_num', dest='num_fea', type=int, default=128, help='number of feature maps in hourglass')
     p.add_argument('--kernel_size', type=int, default=3, help='kernel size for the residual module')
     # additions of this implementation (no dataset / checkpoint ships with the repo)
+    p.add_argument('--in_hw', type=int, default=128, choices=[128, 256, 512],
+                   help='side of the square input crop; the network accepts 128 / 256 / 512 (um_v1.py:99-104), the reference model '
+                   'class hard-codes 128 (hourglass_um_crop_tiny.py:82-87); maps are in_hw/4')
     p.add_argument('--max_steps', type=int, default=0, help='stop after this many optimizer steps (0 = the reference schedule)')
     p.add_argument('--num_frames', type=int, default=0, help='test: number of synthetic frames (0 = dataset exact_num)')
     p.add_argument('--seed', type=int, default=20240)

@@ -12,8 +12,13 @@ What maps to what
   test_model.test (:14-94)                   -> ``test_model`` result file ``name\\t%.4f...`` with '/' -> '\\'
 The reference's datasets and checkpoints are not distributable with this repo: the drivers run on the
 seeded synthetic crop generator (``densereg_amd.data.synthetic``) and random-initialised weights unless
-``load_params`` is given real ones.  Data augmentation (``is_aug``) is a SURVEY 8(f) "next" item: accepted,
-recorded in the model name, not applied.
+``load_params`` is given real ones.  Data augmentation (``--is_aug``, hourglass_um_crop_tiny.py:332-333) is applied
+on the device by ``dr_data_aug`` inside the training loop and recorded in the model name.
+
+Multi-GPU (``--num_gpus N`` under ``torchrun --nproc-per-node N``): ``--batch_size`` is the GLOBAL minibatch and is split
+evenly over the ranks, as the reference splits it over its towers (train_multi_gpu.py:58-62); epochs, ``max_steps`` and the
+learning-rate staircase are therefore the single-GPU ones.  ``--in_hw 256`` / ``512`` selects the larger crops the network
+accepts (um_v1.py:99-104) and the reference model class does not (…tiny.py:82-87).
 """
 from __future__ import annotations
 
@@ -30,35 +35,39 @@ from ..data import preprocess
 from ..data.evaluation import Evaluation
 from ..data.synthetic import DATASETS, make_crops
 from ..network import um_v1
-from ..parallel import DataParallelTrainer, decay_steps
+from ..parallel import DataParallelTrainer, check_world, decay_steps, per_rank_batch
 
 
 class SyntheticDataset:
     """Stand-in for data.icvl/nyu/msra: camera, joint count, sizes; batches come from make_crops."""
 
-    def __init__(self, name: str, subset: str, rank: int = 0):
+    def __init__(self, name: str, subset: str, rank: int = 0, hw: int = 128):
         ds = DATASETS[name]
-        self.name, self.subset, self.rank = name, subset, rank
+        self.name, self.subset, self.rank, self.hw = name, subset, rank, hw
         self.jnt_num = ds['jnt_num']
         self.cfg = (ds['fx'], ds['fy'], ds['cx'], ds['cy'], ds['w'], ds['h'])
         self.approximate_num = ds['approximate_num']
         self.exact_num = ds['exact_num']
 
     def batch(self, batch_size: int, index: int):
-        return make_crops(batch_size, self.name, seed=flags.FLAGS.seed + 7919 * index, rank=self.rank)
+        return make_crops(batch_size, self.name, seed=flags.FLAGS.seed + 7919 * index, rank=self.rank, hw=self.hw)
 
 
 class JointDetectionModel(object):
     _init_lr = 0.001                 # :69
     _lr_decay_factor = 0.1           # :74
     _adam_beta1 = 0.5                # :76
-    _input_height = _input_width = 128      # :82-83
+    _input_height = _input_width = 128      # :82-83 (class defaults; --in_hw overrides them per instance, SURVEY App. C.7)
     _output_height = _output_width = 32     # :86-87
     _base_dir = './exp/train_cache/'        # :92
 
-    def __init__(self, dataset, detect_net, epoch, net_desc='dummy', val_dataset=None, device: int = 0):
+    def __init__(self, dataset, detect_net, epoch, net_desc='dummy', val_dataset=None, device: int = 0, world: int = 1):
         F = flags.FLAGS
         self._dataset, self._val_dataset = dataset, val_dataset
+        self._input_height = self._input_width = int(getattr(F, 'in_hw', 128))
+        self._output_height = self._output_width = self._input_height // 4        # um_v1.py:109
+        self._world = int(world)
+        self._rank_batch = per_rank_batch(F.batch_size, self._world)                # train_multi_gpu.py:58-62
         self._jnt_num = int(dataset.jnt_num)
         self._net, self._net_desc = detect_net, net_desc
         self._num_batches_per_epoch = dataset.approximate_num / float(F.batch_size * F.sub_batch)     # :109
@@ -67,7 +76,7 @@ class JointDetectionModel(object):
         if F.is_aug:
             self._model_desc += '_daug'
         self.device = torch.device('cuda', device)
-        self.engine = um_v1.get_engine(self._jnt_num, self._input_height, F.batch_size, device, bool(F.is_train))
+        self.engine = um_v1.get_engine(self._jnt_num, self._input_height, self._rank_batch, device, bool(F.is_train))
 
     # ---- hyper-parameters (:159-182) -----------------------------------------------------------
     @property
@@ -85,6 +94,11 @@ class JointDetectionModel(object):
     @property
     def max_steps(self):
         return self._max_steps
+
+    @property
+    def rank_batch(self):
+        """crops per micro-step on THIS rank: the global --batch_size split over the ranks"""
+        return self._rank_batch
 
     @property
     def name(self):
@@ -147,7 +161,7 @@ def train(model: JointDetectionModel, dist=None, log=sys.stdout):
         start = time.time()
         ave_loss = 0.0
         for _ in range(F.sub_batch):
-            dm, poses, cfgs, coms, _n = model._dataset.batch(F.batch_size, micro)
+            dm, poses, cfgs, coms, _n = model._dataset.batch(model.rank_batch, micro)
             d_dm, d_pose, d_cfg, d_com = model._t(dm), model._t(poses), model._t(cfgs), model._t(coms)
             if F.is_aug:                                                    # hourglass_um_crop_tiny.py:332-333
                 d_dm, d_pose = preprocess.data_aug(d_dm, d_pose, d_cfg, d_com, generator=aug_rng)
@@ -193,7 +207,7 @@ def test_model(model: JointDetectionModel, out_path: str, log=sys.stdout):
     with open(out_path, 'w') as f:
         while n < total:
             try:
-                dm, poses, cfgs, coms, names = model._val_dataset.batch(F.batch_size, step)
+                dm, poses, cfgs, coms, names = model._val_dataset.batch(model.rank_batch, step)
             except StopIteration:                                           # a record dataset shorter than exact_num
                 break
             xyz = model.test(model._t(dm), model._t(poses), model._t(cfgs), model._t(coms)).cpu().numpy()
@@ -214,8 +228,10 @@ def test_model(model: JointDetectionModel, out_path: str, log=sys.stdout):
 
 def run_train(dataset, val_dataset, dist=None, device=0):
     net_module = __import__('densereg_amd.network.' + flags.FLAGS.net_module, fromlist=['detect_net'])      # :863-867
+    world = dist.get_world_size() if dist is not None else 1
+    check_world(flags.FLAGS.num_gpus, world)
     model = JointDetectionModel(dataset, net_module.detect_net, epoch=flags.FLAGS.epoch, net_desc=net_module.TOWER_NAME,
-                                val_dataset=val_dataset, device=device)
+                                val_dataset=val_dataset, device=device, world=world)
     return model, train(model, dist)
 
 
@@ -259,9 +275,11 @@ def main(argv=None):
         val_dataset = get_dataset(F.dataset, 'testing', F.data_dir, F.pid)
         dataset.rank, dataset.world, dataset.seed = rank, world, F.seed
     else:
-        dataset = SyntheticDataset(F.dataset, 'training', rank)
-        val_dataset = SyntheticDataset(F.dataset, 'testing', rank)
-    eng = um_v1.get_engine(dataset.jnt_num, 128, F.batch_size, local, bool(F.is_train))
+        dataset = SyntheticDataset(F.dataset, 'training', rank, F.in_hw)
+        val_dataset = SyntheticDataset(F.dataset, 'testing', rank, F.in_hw)
+    if F.is_train:
+        check_world(F.num_gpus, world)
+    eng = um_v1.get_engine(dataset.jnt_num, F.in_hw, per_rank_batch(F.batch_size, world if F.is_train else 1), local, bool(F.is_train))
     eng.load_params(_random_params(eng))
     if F.is_train:
         run_train(dataset, val_dataset, dist, local)

@@ -21,8 +21,24 @@ LR_DECAY = 0.1             # :74
 GRAD_CLIP = 0.2            # train_single_gpu.py:86
 
 
+def per_rank_batch(global_batch: int, world: int) -> int:
+    """``--batch_size`` is the GLOBAL minibatch, split evenly over the ranks like the reference splits it over its towers
+    (train_multi_gpu.py:58-62: ``assert FLAGS.batch_size % FLAGS.num_gpus == 0`` + ``tf.split``)."""
+    if world < 1 or global_batch % world != 0:
+        raise ValueError('the batch_size should be divisible wrt num_gpus (batch_size=%d, num_gpus=%d)' % (global_batch, world))
+    return global_batch // world
+
+
+def check_world(num_gpus: int, world: int) -> None:
+    """``--num_gpus`` must name the number of ranks the launcher started (one process per GPU)."""
+    if num_gpus != world:
+        raise ValueError('--num_gpus %d but the launcher started %d rank(s): launch with torchrun --nproc-per-node %d, '
+                         'or pass --num_gpus %d' % (num_gpus, world, num_gpus, world))
+
+
 def decay_steps(dataset: str, batch_size: int, sub_batch: int) -> float:
-    """hourglass_um_crop_tiny.py:109,174: (approximate_num / (batch*sub_batch)) * epochs_per_decay (a float)."""
+    """hourglass_um_crop_tiny.py:109,174: (approximate_num / (batch*sub_batch)) * epochs_per_decay (a float).
+    ``batch_size`` is the GLOBAL batch (all ranks together), as in the reference."""
     ds = DATASETS[dataset]
     return ds['approximate_num'] / float(batch_size * sub_batch) * ds['epochs_per_decay']
 
@@ -34,6 +50,9 @@ def learning_rate(step: int, dataset: str, batch_size: int, sub_batch: int) -> f
 
 class DataParallelTrainer:
     def __init__(self, engine, dataset: str = 'nyu', sub_batch: int = 5, dist=None, all_reduce=None):
+        """``micro_step`` takes this rank's share of the minibatch; the learning-rate staircase counts optimizer steps
+        of the GLOBAL batch (``batch * world`` crops per micro-step), so a run on N ranks sees the same number of epochs
+        and decays at the same point in the data as the single-GPU run of the reference."""
         self.eng = engine
         self.dataset = dataset
         self.sub_batch = int(sub_batch)
@@ -67,7 +86,7 @@ class DataParallelTrainer:
     def optimizer_step(self, batch_size: int):
         """``sess.run(train_op)`` (:150) then ``reset_op`` (:144)."""
         self.reduce_gradients()
-        lr = learning_rate(self.global_step, self.dataset, batch_size, self.sub_batch)
+        lr = learning_rate(self.global_step, self.dataset, batch_size * self.world, self.sub_batch)
         self.global_step += 1
         self.eng.apply_adam(lr, float(self.sub_batch * self.world), self.global_step, GRAD_CLIP)
         self.eng.zero_grad()

@@ -146,6 +146,8 @@ def test_engine_export_restore_round_trip(emu, tmp_path):
     names = ck.export_from(h, prefix, global_step=40)
     assert 'global_step' in names and 'Conv_2/BatchReNorm/Conv_2/BatchReNorm/moving_mean/biased' in names
     tensors = ck.read_checkpoint(prefix)
+    # train_single_gpu.py:42: global_step is a float32 variable in the reference graph; Saver.restore checks the dtype
+    assert tensors['global_step'].dtype == np.float32 and tensors['global_step'].shape == () and float(tensors['global_step']) == 40.0
     assert [n for n, _, _ in param_specs(cfg)] == [n for n in [p[0] for p in h.param_infos()]]
     # what a reference checkpoint additionally holds: Adam slots and the beta powers
     tensors['Conv/weights/Adam'] = np.zeros_like(tensors['Conv/weights'])

@@ -173,6 +173,31 @@ def test_crop_from_bbx_and_center_of_mass_identity(be):
         np.testing.assert_allclose(com[b], F.center_of_mass(sq[b], cf[b]), rtol=2e-6)
 
 
+def test_crop_from_bbx_outside_the_frame_and_degenerate(be):
+    """A box is data: one that leaves the frame (negative corner, beyond H/W) must not read out of bounds -- the missing
+    pixels are background, i.e. the result equals the oracle run on the frame embedded in a larger zero canvas -- and a
+    zero-area box leaves a finite crop camera (the reference's crop_to_bounding_box raises on both)."""
+    rng = np.random.default_rng(11)
+    B, H, W, P = 3, 48, 64, 40
+    dms = rng.uniform(200, 900, (B, H, W)).astype(np.float32)
+    cfgs = np.tile(np.array([200.0, 210.0, 32.0, 24.0, W, H], np.float32), (B, 1))
+    bbx = np.array([[-10, -7, 30, 40, 1e9], [20, 30, H + 15, W + 9, 1e9], [-5, -5, H + 5, W + 5, 600.0]], np.float32)
+    crops, ncfg, com = _crop_abi(be, dms, None, cfgs, False, out_hw=32, bbx=bbx)
+    assert np.isfinite(crops).all() and np.isfinite(ncfg).all() and np.isfinite(com).all()
+    for b in range(B):
+        canvas = np.zeros((H + 2 * P, W + 2 * P), np.float32)
+        canvas[P:P + H, P:P + W] = dms[b]
+        shifted = bbx[b] + np.array([P, P, P, P, 0], np.float32)
+        ccfg = cfgs[b] + np.array([0, 0, P, P, 0, 0], np.float32)
+        rc, _, rcfg = F.crop_from_bbx(canvas, None, shifted, ccfg, 32, 32)
+        assert np.abs(crops[b] - rc).max() < 2e-3, b
+        np.testing.assert_allclose(ncfg[b], rcfg, rtol=1e-5, atol=1e-4)
+    flat = np.array([[10, 10, 10, 10, 1e9], [20, 5, 12, 3, 1e9]], np.float32)          # no area / inverted
+    crops, ncfg, com = _crop_abi(be, dms[:2], None, cfgs[:2], False, out_hw=32, bbx=flat)
+    assert np.isfinite(crops).all() and np.isfinite(ncfg).all() and np.isfinite(com).all()
+    assert (crops == 0).all() and (com[:, 2] == 200.0).all()
+
+
 def test_crop_from_bbx_on_the_reference_nyu_boxes(be):
     """tests/golden/nyu_bbx_head.npy = the first 16 rows of the reference's data/nyu_bbx.pkl (data, not code): they pin the
     (top, left, bottom, right, depth threshold) convention of crop_from_bbx (data/preprocess.py:81-129; call site

@@ -63,12 +63,73 @@ def test_lr_schedule_and_model_naming():
     flags.parse([])
 
 
-def test_evaluation_metrics_and_curve(tmp_path):
+def test_global_batch_is_split_over_ranks_like_the_reference_towers():
+    """train_multi_gpu.py:58-62: --batch_size is the GLOBAL batch, split evenly over num_gpus; epochs / max_steps / the
+    learning-rate staircase are those of the single-GPU run (BASELINE config 4: MSRA batch 320 on 8 GPUs = 40 per rank)."""
+    from densereg_amd import flags
+    from densereg_amd.model import hourglass_um_crop_tiny as M
+    from densereg_amd.parallel import DataParallelTrainer, check_world, decay_steps, learning_rate, per_rank_batch
+    assert per_rank_batch(320, 8) == 40 and per_rank_batch(40, 1) == 40
+    with pytest.raises(ValueError, match='divisible'):
+        per_rank_batch(40, 3)
+    check_world(8, 8)
+    with pytest.raises(ValueError, match='--num_gpus 1 but the launcher started 8'):
+        check_world(1, 8)
+    # the trainer's staircase counts optimizer steps of the global batch: 8 ranks x 40 == 1 rank x 320
+    assert abs(decay_steps('msra', 320, 5) - 68085 / 1600.0 * 20) < 1e-9
+
+    class _Dist:
+        @staticmethod
+        def get_world_size():
+            return 8
+    calls = []
+
+    class _Eng:
+        def flat_view(self, which): return None
+        def zero_grad(self): pass
+        def apply_adam(self, lr, div, step, clip): calls.append((lr, div, step))
+    tr = DataParallelTrainer(_Eng(), dataset='msra', sub_batch=5, dist=_Dist(), all_reduce=lambda g: None)
+    tr.global_step = int(decay_steps('msra', 320, 5)) + 1           # just past the first decay of the GLOBAL schedule
+    tr.optimizer_step(40)
+    assert math.isclose(calls[0][0], 1e-4) and calls[0][1] == 40.0 and calls[0][2] == tr.global_step
+    assert math.isclose(learning_rate(tr.global_step - 1, 'msra', 320, 5), 1e-4)
+    assert learning_rate(tr.global_step - 1, 'msra', 40, 5) == 1e-3        # what a per-rank-batch schedule would have said
+    # model class: input / map sides follow --in_hw (SURVEY App. C.7), max_steps from the global batch
+    flags.parse(['--dataset', 'msra', '--batch_size', '320', '--num_gpus', '8', '--in_hw', '256'])
+    try:
+        class _DS:
+            name, subset, jnt_num, approximate_num = 'msra', 'training', 21, 68085
+        made = {}
+        orig = M.um_v1.get_engine
+        M.um_v1.get_engine = lambda J, hw, mb, dev, tr_: made.setdefault('args', (J, hw, mb, dev, tr_))
+        model = M.JointDetectionModel(_DS(), None, epoch=80, world=8)
+        assert made['args'][:3] == (21, 256, 40) and model.rank_batch == 40
+        assert model._input_height == 256 and model._output_height == 64
+        assert model.max_steps == int(80 * 68085 / 1600.0)
+        assert abs(model.decay_steps - 68085 / 1600.0 * 20) < 1e-9
+    finally:
+        M.um_v1.get_engine = orig
+        flags.parse([])
+
+
+def test_evaluation_metrics_and_curve(tmp_path, capsys):
+    """data/evaluation.py:9-18 and the curve file of :63-103, against a HAND-COMPUTED expected file: 17 thresholds
+    5t+0.5, strict '<' for the curve, '<=' for the four printed shares, '%f %f\\n' with the share x 100."""
     from densereg_amd.data.evaluation import Evaluation
     a, b = np.zeros(6), np.array([3, 4, 0, 0, 0, 12.0])
     assert Evaluation.maxJntError(a, b) == 12.0 and Evaluation.meanJntError(a, b) == 8.5     # evaluation.py:9-18
-    th, frac = Evaluation.plotError([1.0, 5.0, 50.0], str(tmp_path / 'e.txt'))
-    assert frac[0] == 0 and abs(frac[10] - 2 / 3) < 1e-9 and frac[-1] == 1.0
+    scores = [50.0, 1.0, 10.6, 5.0, 80.5, 10.5]                     # unsorted on purpose (:64 sorts)
+    th, frac = Evaluation.plotError(scores, str(tmp_path / 'e.txt'))
+    below = [0, 2, 2, 4, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5]     # scores strictly below 0.5, 5.5, 10.5, ... 80.5
+    expected = ''.join('%f %f\n' % (5.0 * t + 0.5, n / 6.0 * 100.0) for t, n in enumerate(below))
+    assert open(tmp_path / 'e.txt').read() == expected
+    assert expected.splitlines()[0] == '0.500000 0.000000' and expected.splitlines()[2] == '10.500000 33.333333'
+    assert expected.splitlines()[-1] == '80.500000 83.333333' and len(expected.splitlines()) == 17
+    assert th == [5.0 * t + 0.5 for t in range(17)] and frac[3] == 4 / 6.0
+    out = capsys.readouterr().out.splitlines()                      # 10.5 counts for '<=' but not for '<'
+    assert out == ['10mm percentage: 0.500000', '20mm percentage: 0.666667', '30mm percentage: 0.666667', '40mm percentage: 0.666667']
+    th2, frac2 = Evaluation.averageMaxJntError(scores, log=None)    # :21-61 returns the same curve
+    assert th2 == th and frac2 == frac
 
 
 def test_synthetic_dataset_constants():
@@ -152,6 +213,13 @@ def test_engine_checkpoint_round_trip_with_adam(gpu, tmp_path):
     steps(a, ta, 2)
     prefix = str(tmp_path / 'model.ckpt-2')
     names = a.save_checkpoint(prefix, global_step=2)
+    # everything Saver(tf.global_variables()).restore looks up by name: Adam's non-slot variables hold beta^(t+1) after
+    # t updates, global_step is float32 (train_single_gpu.py:42)
+    assert {'beta1_power', 'beta2_power', 'global_step'} <= set(names)
+    from densereg_amd import checkpoint as _ck
+    sc = _ck.read_checkpoint(prefix, names=['beta1_power', 'beta2_power', 'global_step'])
+    assert sc['global_step'].dtype == np.float32 and float(sc['global_step']) == 2.0
+    assert abs(float(sc['beta1_power']) - 0.5 ** 3) < 1e-7 and abs(float(sc['beta2_power']) - 0.999 ** 3) < 1e-7
     assert 'hg_imgproc/Conv/weights/Adam_1' in names and 'global_step' in names
     assert int(ck.read_checkpoint(prefix, names=['global_step'])['global_step']) == 2
     b = fresh()

@@ -1,9 +1,12 @@
 #!/usr/bin/env python
 """bench.py -- depth-crops/sec of the hot path on N MI355X (one process per GPU).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 100 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          (no launcher: re-executes itself under torch.distributed.run with N ranks)
+
+The number of ranks must equal --gpus: a mismatch is an error, never a silent one-GPU measurement.
 
 A "step" is one pass of the hot path over one batch of 40 synthetic 128x128 crops per GPU, inputs
 resident in HBM before the timed region:
@@ -12,14 +15,18 @@ resident in HBM before the timed region:
         all-reduces the flat gradient over RCCL (N>1) and applies clip+Adam -- BASELINE.json config 3/4.
   --mode infer: ICVL S=2 F=128 J=16 B=40 forward(eval) + vote -> xyz -- BASELINE.json config 2.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
-HIP-event timed in a separate profiled pass over the same workload) and `cpu_baseline` (the CPU
-oracle restatement timed on the host cores, rank 0 / N=1 only).
+HIP-event timed in a separate profiled pass over the same workload), `cpu_baseline` (the CPU
+oracle restatement timed on the host cores, rank 0 / N=1 only) and, in train mode, `forward_vote`: the
+other north-star figure (ICVL forward(eval)+vote crops/s, same N, same process) -- `metric`/`value`
+stay the fwd+bwd headline.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,8 +46,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--mode', choices=['train', 'infer'], default=os.environ.get('DR_BENCH_MODE', 'train'))
     ap.add_argument('--batch', type=int, default=40)
     ap.add_argument('--sub_batch', type=int, default=5)
@@ -54,12 +61,17 @@ def parse():
                     help='matrix-core arithmetic of the convolutions; bf16 = BASELINE config 5\'s conv path (fp32 stays the headline)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--no-forward-vote', action='store_true', help='train mode: skip the forward(eval)+vote leg')
     ap.add_argument('--detail', default='', help='write a per-layer timing table (markdown) to this path')
     return ap.parse_args()
 
 
 def cpu_baseline(mode, cfg_tuple, B, dataset):
-    """The CPU oracle (PyTorch-CPU restatement of the reference graph, NOT TF1.3) on the host cores."""
+    """The CPU oracle (PyTorch-CPU restatement of the reference graph, NOT TF1.3) on the host cores: the full B-crop
+    step of the benchmarked workload (B=40), median over the timed iterations.  Bounded to ~25 s of CPU work,
+    so fewer than SURVEY's 3+10 iterations fit on the training step -- the sample string says how many ran.  Timed with
+    every core the process may use and, when that is more than 32, also with 32 threads (oneDNN often scales worse past
+    that on a cgroup-limited box); the better of the two is reported with its thread count."""
     from oracle import net, pose, train
     from oracle.graph import NetConfig
     S, F, J = cfg_tuple
@@ -68,31 +80,38 @@ def cpu_baseline(mode, cfg_tuple, B, dataset):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    ncores = max(1, min(avail, 32))      # oneDNN stops scaling (and oversubscribes cgroup-limited boxes) beyond this
-    torch.set_num_threads(ncores)
-    Bc = min(B, 8)                       # bounded sample: same workload, 8-crop batches
-    dm, poses, cfgs, coms, _ = make_crops(Bc, dataset, seed=999)
+    dm, poses, cfgs, coms, _ = make_crops(B, dataset, seed=999)
     ndm = pose.norm_dm(dm, coms)
     params = net.init_params(cfg, 7)
-    times = []
-    budget_s, t_start = 20.0, time.time()
-    it = 0
-    while it < 11 and (time.time() - t_start < budget_s or it < 2):
-        t0 = time.time()
+
+    def one():
         if mode == 'infer':
             ep = net.forward_eval(cfg, params, ndm)
             pose.estimate_pose_mm(ep['hm_outs'][-1], ep['hm3_outs'][-1], ep['um_outs'][-1], ndm, cfgs, coms)
         else:
             train.loss_and_grads(cfg, params, ndm, poses, cfgs, coms)
-        dt = time.time() - t0
-        if it >= 1:                      # first iteration = warm-up
-            times.append(dt)
-        it += 1
-    med = float(np.median(times))
-    return {'value': Bc / med, 'unit': 'crops/s', 'cores': ncores, 'kind': 'port',
-            'sample': '%d timed iterations (after 1 warm-up) of one B=%d %s step on the CPU oracle (PyTorch-CPU fp32, '
-                      'oneDNN, %d threads of %d available), median'
-                      % (len(times), Bc, 'fwd(eval)+vote' if mode == 'infer' else 'fwd+bwd', ncores, avail)}
+
+    def leg(threads, budget_s, warm, most):
+        torch.set_num_threads(threads)
+        times, t_start, it = [], time.time(), 0
+        while it < warm + most and (time.time() - t_start < budget_s or it < warm + 2):
+            t0 = time.time()
+            one()
+            if it >= warm:
+                times.append(time.time() - t0)
+            it += 1
+        return float(np.median(times)), len(times)
+
+    legs = [(avail,) + leg(avail, 13.0, 1, 10)]
+    if avail > 32:
+        legs.append((32,) + leg(32, 13.0, 1, 10))
+    cores, med, n = min(legs, key=lambda l: l[1])
+    others = ', '.join('%d threads: %.1f crops/s' % (c, B / m) for c, m, _ in legs if c != cores)
+    return {'value': B / med, 'unit': 'crops/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d timed iterations (after 1 warm-up; ~13 s budget per leg) of the full B=%d %s step on the CPU oracle '
+                      '(PyTorch-CPU fp32, oneDNN), median; %d of %d available cores used%s'
+                      % (n, B, 'fwd(eval)+vote' if mode == 'infer' else 'fwd+loss+bwd', cores, avail,
+                         (' (also timed: ' + others + ')') if others else '')}
 
 
 def pmc_traffic(mode, kernel):
@@ -106,8 +125,29 @@ def pmc_traffic(mode, kernel):
         return None
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: run N ranks under torch.distributed.run (one per GPU, RCCL)."""
+    ngpu = torch.cuda.device_count()
+    if ngpu < args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) are visible; refusing to measure fewer ranks than asked\n'
+                         % (args.gpus, ngpu))
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit('bench.py: --gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
     # stdout carries exactly ONE line, the JSON: anything else written to file descriptor 1 during the run (RCCL prints a
     # version banner there from C when the first communicator is created) goes to stderr instead
     sys.stdout.flush()
@@ -115,6 +155,9 @@ def main():
     os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree\n' % (args.gpus, world))
+        sys.exit(2)
     # one rank per GPU; if the launcher narrows device visibility to one GPU per process, that GPU is index 0
     local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)                        # before the process group: RCCL binds to the current device
@@ -124,7 +167,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, 'launch N>1 through torch.distributed.run'
+        assert dist.get_world_size() == args.gpus or world == 1
     dev = torch.device('cuda', local)
 
     from densereg_amd import _lib
@@ -142,17 +185,19 @@ def main():
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
 
     # random-init weights of the named architecture (values are irrelevant to dense conv speed)
-    rng = np.random.default_rng(7)
-    params = {}
-    for name, shape, _ in eng.param_infos():
-        leaf = name.rsplit('/', 1)[1]
-        if leaf == 'weights':
-            params[name] = (rng.standard_normal(shape) * np.sqrt(2.0 / (shape[0] * shape[1] * shape[2]))).astype(np.float32)
-        elif leaf in ('gamma', 'moving_variance', 'r_max'):
-            params[name] = np.ones(shape, np.float32)
-        else:
-            params[name] = np.zeros(shape, np.float32)
-    eng.load_params(params)
+    def random_params(e):
+        rng = np.random.default_rng(7)
+        params = {}
+        for name, shape, _ in e.param_infos():
+            leaf = name.rsplit('/', 1)[1]
+            if leaf == 'weights':
+                params[name] = (rng.standard_normal(shape) * np.sqrt(2.0 / (shape[0] * shape[1] * shape[2]))).astype(np.float32)
+            elif leaf in ('gamma', 'moving_variance', 'r_max'):
+                params[name] = np.ones(shape, np.float32)
+            else:
+                params[name] = np.zeros(shape, np.float32)
+        return params
+    eng.load_params(random_params(eng))
 
     dm, poses, cfgs, coms, _ = make_crops(B, dataset, seed=20240, rank=rank, hw=HW)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -173,18 +218,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed(fn):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize, MAX over ranks (seconds)."""
+        for i in range(args.warmup):
+            fn(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            fn(args.warmup + i)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
+    dt = timed(step)
 
     # ---- roofline leg: separate profiled pass (events around every op), same workload ------------
     roof = None
@@ -221,9 +271,35 @@ def main():
                                                 'gbs': (s['bytes'] / (s['total_ms'] * 1e-3) / 1e9) if s['bytes'] else None}
                                     for s in stats}}
 
+    # ---- the other north-star figure, same process, same N: forward(eval) + vote on ICVL crops (replicas, no collective) ----
+    fwd_vote = None
+    if mode == 'train' and not args.no_forward_vote:
+        Ji = DATASETS['icvl']['jnt_num']
+        ieng = Engine(S, F, Ji, HW, 3, B, local, training=False)
+        if bf16:
+            ieng.set_precision('bf16')
+        ieng.load_params(random_params(ieng))
+        idm, _ip, icfg, icom, _ = make_crops(B, 'icvl', seed=20240, rank=rank, hw=HW)
+        i_dm, i_cfg, i_com = ieng.norm_dm(t(idm), t(icom)), t(icfg), t(icom)
+        i_xyz = ieng.new(B, 3 * Ji)
+        idt = timed(lambda i: ieng.infer(i_dm, i_cfg, i_com, out=i_xyz))
+        fwd_vote = {'metric': 'depth-crops/sec fwd(eval)+vote, %d-stack fea=%d @%dx%d' % (S, F, HW, HW),
+                    'value': B * world * args.steps / idt, 'unit': 'crops/s', 'ms_per_step': idt / args.steps * 1e3,
+                    'steps': args.steps, 'warmup': args.warmup,
+                    'workload': 'ICVL S=%d F=%d J=%d B=%d/GPU %dx%d forward(eval) + vote -> xyz mm, %d replica(s)' % (S, F, Ji, B, HW, HW, world),
+                    'conv_gflop_per_crop_fwd': ieng.conv_flops_per_crop() / 1e9}
+        ieng.close()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(mode, (S, F, J), B, dataset) if HW == 128 else None
+
+    rccl = None
+    if dist is not None:
+        try:
+            rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = 'unknown'
 
     if rank == 0:
         crops = B * world * args.steps
@@ -237,8 +313,9 @@ def main():
                         if mode == 'train' else 'forward(eval) + vote -> xyz mm') +
                        (', bf16 matrix cores on fp32 tensors (fp32 accumulate, epilogues, vote)' if bf16 else ''),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                       'world_size': dist.get_world_size() if dist is not None else 1, 'rccl_version': rccl,
                        'conv_gflop_per_crop_fwd': eng.conv_flops_per_crop() / 1e9},
-            'roofline': roof, 'cpu_baseline': cpu,
+            'roofline': roof, 'cpu_baseline': cpu, 'forward_vote': fwd_vote,
         }
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:

@@ -25,6 +25,19 @@ class KernelStat(C.Structure):
                 ('bytes', C.c_double)]
 
 
+class DbgBnArgs(C.Structure):
+    """include/densereg_debug.h: dr_dbg_bn_args (test hook)."""
+    _fields_ = [('B', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('k', C.c_int),
+                ('x', C.c_void_p), ('x_cs', C.c_int), ('w', C.c_void_p),
+                ('gamma', C.c_void_p), ('beta', C.c_void_p), ('mm', C.c_void_p), ('mv', C.c_void_p),
+                ('r_max', C.c_float), ('d_max', C.c_float), ('relu', C.c_int),
+                ('res', C.c_void_p), ('dout', C.c_void_p),
+                ('gr', C.c_void_p), ('gr_cs', C.c_int), ('wr', C.c_void_p), ('kr', C.c_int), ('Cr', C.c_int),
+                ('y', C.c_void_p), ('raw', C.c_void_p), ('bnc', C.c_void_p), ('mm_next', C.c_void_p), ('mv_next', C.c_void_p),
+                ('dout_used', C.c_void_p), ('draw', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p),
+                ('dres', C.c_void_p), ('fwd_rows', C.c_int), ('bwd_rows', C.c_int)]
+
+
 class DenseRegError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__('densereg error %d: %s' % (code, msg))
@@ -76,6 +89,7 @@ SIGNATURES = {
     'dr_dbg_bn_bench': (_i, [C.c_long, _i, _i, _i, C.POINTER(C.c_float)]),
     'dr_dbg_wgrad': (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, C.c_float, _i, _i, _vp, _vp]),
     'dr_dbg_mfma_peak': (_i, [_i, _i, _i, C.POINTER(C.c_float)]),
+    'dr_dbg_bn_layer': (_i, [C.POINTER(DbgBnArgs), _vp]),
     'dr_profile_enable': (_i, [_vp, _i]),
     'dr_profile_read': (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
     'dr_profile_detail': (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),

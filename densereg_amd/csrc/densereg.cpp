@@ -1280,6 +1280,103 @@ extern "C" int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const
     return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
 }
 
+// One conv -> BatchReNorm(train) layer, forward + backward, with the executors' launch logic (densereg_debug.h).
+extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
+    if (!a || !a->x || !a->w || !a->gamma || !a->beta || !a->mm || !a->mv || !a->y || !a->raw || !a->bnc || !a->mm_next ||
+        !a->mv_next || !a->draw || !a->dgamma || !a->dbeta || !a->dout_used)
+        return DR_E_INVALID;
+    if ((a->k != 1 && a->k != 3) || (!a->dout && !(a->gr && a->wr && (a->kr == 1 || a->kr == 3) && a->Cr > 0))) return DR_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int C = a->Cout, cs = dr_round_up(C, 4), taps = a->k * a->k;
+    const long M = (long)a->B * a->H * a->W;
+    const int Kp = dr_round_up(a->Cin, 16), Np = dr_round_up(C, 32);
+    std::vector<void*> tmp;
+    auto alloc = [&](size_t bytes) { void* q = rt::dmalloc(std::max<size_t>(bytes, 16)); tmp.push_back(q); return q; };
+    float* wp = (float*)alloc((size_t)taps * Kp * Np * 4);
+    float* zeros = (float*)alloc(256);
+    float* small = (float*)alloc((size_t)(2 + 2 + 3) * C * 4);           // scale|shift, shadow mean|var, coef[3]
+    double* part = (double*)alloc((size_t)std::max<long>((M + 31) / 32, 1024) * 2 * C * 8);
+    double* part2 = (double*)alloc((size_t)std::max<long>((M + 31) / 32, 1024) * 2 * C * 8);
+    bool ok = true;
+    for (void* q : tmp) ok = ok && q;
+    float* wpT = nullptr;
+    int KpT = 0, NpT = 0;
+    if (ok && !a->dout) {
+        KpT = dr_round_up(a->Cr, 16); NpT = dr_round_up(C, 32);
+        wpT = (float*)alloc((size_t)a->kr * a->kr * KpT * NpT * 4);
+        ok = ok && wpT;
+    }
+    auto cleanup = [&]() { for (void* q : tmp) if (q) rt::dfree(q); };
+    if (!ok) { cleanup(); return DR_E_NOMEM; }
+    rt::memset_async(zeros, 0, 256, s);
+    rt::memset_async(small, 0, (size_t)7 * C * 4, s);
+    rt::memset_async(a->dgamma, 0, (size_t)C * 4, s);
+    rt::memset_async(a->dbeta, 0, (size_t)C * 4, s);
+    float* scale = small; float* shift = small + C;
+    // ---- forward: run_conv_train ---------------------------------------------------------------
+    DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, a->w, wp, taps, a->Cin, C, Kp, Np);
+    ConvParams p{};
+    p.x = a->x; p.x_cs = a->x_cs; p.Cin = a->Cin; p.B = a->B; p.H = a->H; p.W = a->W; p.ksize = a->k;
+    p.w = wp; p.Kp = Kp; p.Np = Np; p.y = a->raw; p.y_cs = cs; p.Cout = C; p.stat_part = part; p.zeros = zeros;
+    a->fwd_rows = conv_stat_rows(p);
+    int rc = launch_conv_igemm(p, s);
+    BnTrainParams fp{};
+    fp.raw = a->raw; fp.raw_cs = cs; fp.M = M; fp.C = C; fp.part = part; fp.part_rows = a->fwd_rows;
+    fp.beta = a->beta; fp.gamma = a->gamma; fp.mm = a->mm; fp.mv = a->mv; fp.mm_next = a->mm_next; fp.mv_next = a->mv_next;
+    fp.shadow_mean = small + 2 * C; fp.shadow_var = small + 3 * C; fp.shadow_step = 1;
+    fp.r_max = a->r_max; fp.d_max = a->d_max; fp.eps = 0.001f; fp.decay = 0.99f;
+    fp.scale = scale; fp.shift = shift; fp.bnc = a->bnc; fp.relu = a->relu ? 1 : 0;
+    fp.res = View{nullptr, 0, 0, 0};
+    if (a->res) fp.res = View{const_cast<float*>(a->res), cs, 0, C};
+    fp.out = View{a->y, cs, 0, C};
+    const int rpb = 256 / (cs / 4);
+    if (!rc) {
+        if (fp.part_rows <= kBnFuseRows) {
+            DR_LAUNCH(bn_train_apply_kernel<true>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, fp);
+        } else {
+            DR_LAUNCH(bn_fwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, s, fp);
+            DR_LAUNCH(bn_train_apply_kernel<false>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, fp);
+        }
+    }
+    // ---- backward: backward_conv (BatchReNorm part) ------------------------------------------------
+    BnBwdParams bp{};
+    bp.raw = a->raw; bp.raw_cs = cs; bp.M = M; bp.C = C; bp.relu = a->relu ? 1 : 0;
+    bp.scale = scale; bp.shift = shift; bp.bnc = a->bnc; bp.gamma = a->gamma;
+    bp.coef = small + 4 * C; bp.dbeta = a->dbeta; bp.dgamma = a->dgamma; bp.draw = a->draw;
+    if (a->res && a->dres) { bp.dres = View{a->dres, cs, 0, C}; bp.dres_acc = 0; }
+    if (!rc && a->dout) {
+        rt::d2d(a->dout_used, a->dout, (size_t)M * cs * 4, s);
+        bp.dout = View{a->dout_used, cs, 0, C};
+        bp.part = part; bp.part_rows = grid_for(M, rpb * 8, 256);
+        DR_LAUNCH(bn_bwd_reduce_kernel, dim3(bp.part_rows), dim3(256), 0, s, bp);
+    } else if (!rc) {
+        const int tr = a->kr * a->kr;
+        DR_LAUNCH(pack_weights_T_kernel, dim3(grid_for((long)tr * KpT * NpT)), dim3(256), 0, s, a->wr, wpT, tr, C, a->Cr, KpT, NpT);
+        ConvParams q{};
+        q.x = a->gr; q.x_cs = a->gr_cs; q.Cin = a->Cr; q.B = a->B; q.H = a->H; q.W = a->W; q.ksize = a->kr;
+        q.w = wpT; q.Kp = KpT; q.Np = NpT; q.y = a->dout_used; q.y_cs = cs; q.Cout = C; q.zeros = zeros;
+        q.stat_part = part2; q.bst_raw = a->raw; q.bst_cs = cs; q.bst_relu = a->relu ? 1 : 0;
+        q.bst_scale = scale; q.bst_shift = shift; q.bst_bnc = a->bnc;
+        bp.dout = View{a->dout_used, cs, 0, C};
+        bp.part = part2; bp.part_rows = conv_stat_rows(q);
+        rc = launch_conv_igemm(q, s);
+    }
+    a->bwd_rows = bp.part_rows;
+    if (!rc) {
+        if (bp.part_rows <= kBnFuseRows) {
+            DR_LAUNCH(bn_bwd_apply_kernel<true>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, bp);
+        } else {
+            DR_LAUNCH(bn_bwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, s, bp);
+            DR_LAUNCH(bn_bwd_apply_kernel<false>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, bp);
+        }
+    }
+    rt::sync_stream(s);
+    cleanup();
+    std::string m;
+    if (rc || rt::last_error(&m)) return DR_E_DEVICE;
+    return DR_OK;
+}
+
 // Micro-benchmark of the weight-gradient kernel + slab fold on self-allocated buffers: microseconds per call for a
 // given channel tile T and slab count nsplit (0 = the executor's planner).
 extern "C" int dr_dbg_wgrad_bench(int B, int H, int W, int Cin, int Cout, int k, int T, int nsplit, int iters, float* us_out,

@@ -31,6 +31,33 @@ int dr_dbg_wgrad_bench(int B, int H, int W, int Cin, int Cout, int k, int T, int
  * of (train apply, backward reduce, backward apply).  reduce_blocks > 0 overrides the backward-reduce grid. */
 int dr_dbg_bn_bench(long M, int C, int reduce_blocks, int iters, float* us_out);
 
+/* ONE conv -> BatchReNorm(train) [-> ReLU] [+ residual] layer, forward and backward, through exactly the kernels and the
+ * launch logic the executors use (train_exec.inc: run_conv_train / backward_conv), on caller buffers -- so the train-mode
+ * BatchReNorm kernels can be pinned against an fp64 autograd of the same layer (network/slim/ops.py:130-171).
+ * Tensors are NHWC with channel stride cs = round_up(Cout, 4) unless a stride is given.  Backward seed: either `dout`
+ * (the layer runs its own reduce pass) or a consumer convolution (`gr`, `wr`: kr x kr, Cout -> Cr): then dOut is
+ * produced by that consumer's dgrad launch, which also computes the layer's backward sums in its epilogue (the
+ * "single reader" path of plan_backward).  All pointers are device pointers; synchronises the stream. */
+typedef struct dr_dbg_bn_args {
+    int B, H, W, Cin, Cout, k;
+    const float* x; int x_cs;                 /* layer input */
+    const float* w;                           /* HWIO (k,k,Cin,Cout) */
+    const float* gamma; const float* beta; const float* mm; const float* mv;      /* [Cout]; mm/mv = moving stats before */
+    float r_max, d_max; int relu;
+    const float* res;                         /* nullable: residual added after the activation, [M][cs] */
+    const float* dout;                        /* [M][cs], or NULL when a consumer is given */
+    const float* gr; int gr_cs; const float* wr; int kr; int Cr;
+    float* y; float* raw;                     /* out: activation and raw conv output, [M][cs] */
+    float* bnc;                               /* out: [4][Cout] mean, inv_std, r, d of this step */
+    float* mm_next; float* mv_next;           /* out: moving stats after (zero-debiased first update) */
+    float* dout_used;                         /* out: the dOut the backward saw, [M][cs] */
+    float* draw;                              /* out: gradient wrt the raw conv output, [M][cs] */
+    float* dgamma; float* dbeta;              /* out: [Cout] */
+    float* dres;                              /* out, nullable: gradient of the residual input, [M][cs] */
+    int fwd_rows, bwd_rows;                   /* out: partial rows of the two reductions (which finalize path ran) */
+} dr_dbg_bn_args;
+int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream);
+
 /* Micro-benchmark one conv shape on self-allocated buffers: average milliseconds per launch.
  * tile = -1 (heuristic) or a tile id (0 128x128, 1 64x128, 2 128x64, 3 64x64, 4 128x32);
  * abl = 0 product kernel, 1/2/3 = ablations of the 128x128 kernel (no refills / no MFMA / no stores),

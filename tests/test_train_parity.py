@@ -35,7 +35,7 @@ def _case(S, F, J, B, dataset='icvl'):
     return cfg, params, ndm, poses, cfgs, coms
 
 
-def _run_step(be, cfg, params, ndm, poses, cfgs, coms, masks):
+def _run_step(be, cfg, params, ndm, poses, cfgs, coms, masks, ref64=True):
     import torch
     from oracle import net, train
     B, S, J = ndm.shape[0], cfg.num_stack, cfg.num_jnt
@@ -64,7 +64,10 @@ def _run_step(be, cfg, params, ndm, poses, cfgs, coms, masks):
     h.call('dr_backward', B, be.stream)
     be.sync()
     g = flat_grads_by_name(be, h, cfg)
-    _, g64, _, _ = train.loss_and_grads(cfg, params, ndm, poses, cfgs, coms, dropout_masks=masks, dtype=torch.float64)
+    if ref64:
+        _, g64, _, _ = train.loss_and_grads(cfg, params, ndm, poses, cfgs, coms, dropout_masks=masks, dtype=torch.float64)
+    else:                                      # host without the memory for the fp64 autograd: fp32 against fp32, two noises
+        g64 = g32
     e_eng, e_o32 = [], []
     for name, ref in g64.items():
         sc = np.abs(ref).max() + 1e-12
@@ -73,8 +76,11 @@ def _run_step(be, cfg, params, ndm, poses, cfgs, coms, masks):
     e_eng, e_o32 = np.array(e_eng), np.array(e_o32)
     print('grad error vs fp64 oracle: engine max %.2e median %.2e | torch-fp32 max %.2e median %.2e'
           % (e_eng.max(), np.median(e_eng), e_o32.max(), np.median(e_o32)))
-    assert e_eng.max() < 6e-2 and np.median(e_eng) < 1e-2
-    assert np.median(e_eng) < 2 * np.median(e_o32) + 1e-4
+    if ref64:
+        assert e_eng.max() < 6e-2 and np.median(e_eng) < 1e-2
+        assert np.median(e_eng) < 2 * np.median(e_o32) + 1e-4
+    else:
+        assert e_eng.max() < 1.2e-1 and np.median(e_eng) < 2e-2
     # a second loss+backward on the same forward must add exactly the same gradient again: catches gradient
     # buffers that are neither zeroed nor overwritten by their first writer (train_exec.inc plan_backward)
     h.call('dr_loss', B, be.ptr(d_dm), be.ptr(d_pose), be.ptr(d_cfg), be.ptr(d_com), be.ptr(d_lo), be.stream)

@@ -54,6 +54,11 @@ struct ConvParams {
     // stat_part rows hold sum(g) and sum(g*yhat), g = dOut * [raw*scale+shift > 0], yhat = (raw-mean)*inv_std, instead
     // of the forward moments.  bst_raw is the layer's raw conv output (row stride bst_cs), bst_bnc = [mean | inv_std].
     const float* bst_raw; int bst_cs; const float* bst_scale; const float* bst_shift; const float* bst_bnc; int bst_relu;
+    // bst_act != 0 -- the same idea for a BIAS conv with ReLU / dropout whose output has no other consumer (um_full 1/2):
+    // bst_raw is that layer's OUTPUT (post ReLU and dropout), bst_scale / bst_shift / bst_bnc are null; the epilogue writes
+    // g = dOut * bst_factor * [out > 0] (the gradient wrt the conv's pre-activation: its act_bwd pass disappears) and the
+    // stat_part rows hold sum(g) = the bias gradient (its column-sum pass disappears too).
+    int bst_act; float bst_factor;
     int Ng;                                // > 0: compute only the first Ng (multiple of 32, <= Np) output columns -- Np
                                            // stays the row stride of the packed weights (input gradients of a concat
                                            // buffer whose last channels have no consumer)

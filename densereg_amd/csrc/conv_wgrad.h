@@ -30,8 +30,10 @@ struct WgradParams {
 // fused by hipcc into one ds_read2_b32); tiles entirely beyond Cin / Cout are skipped.  (A channel-pair mapping
 // read with one ds_read_b64 was measured equal on full tiles and cannot skip anything on ragged ones.)
 // T = 64: one MFMA tile per wave.
+// The kernel body, shared by the one-layer launch (conv_wgrad_kernel) and the grouped launch of many small layers
+// (conv_wgrad_group_kernel): `bid` is the workgroup's index within ITS layer's grid.
 template <int T>
-__global__ __launch_bounds__(256, (T == 128 ? 3 : 6)) void conv_wgrad_kernel(const WgradParams p) {
+__device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int bid) {
     constexpr int BK = 16;                 // pixels per step
     constexpr int ST = T + 4;              // LDS row stride (keeps float4 alignment)
     constexpr int WT = T / 2;              // wave tile
@@ -53,12 +55,12 @@ __global__ __launch_bounds__(256, (T == 128 ? 3 : 6)) void conv_wgrad_kernel(con
     const int tiles = dr_ceil_div(p.Cin, T) * co_tiles;
     int split, rest;
     if ((p.nsplit & 7) == 0) {
-        const int per = p.nsplit >> 3, j = blockIdx.x >> 3;
-        split = (j % per) * 8 + (blockIdx.x & 7);
+        const int per = p.nsplit >> 3, j = bid >> 3;
+        split = (j % per) * 8 + (bid & 7);
         rest = j / per;
     } else {
-        split = blockIdx.x % p.nsplit;
-        rest = blockIdx.x / p.nsplit;
+        split = bid % p.nsplit;
+        rest = bid / p.nsplit;
     }
     const int tile = rest % tiles, tap = rest / tiles;
     const int ci0 = (tile / co_tiles) * T;
@@ -218,6 +220,27 @@ __global__ __launch_bounds__(256, (T == 128 ? 3 : 6)) void conv_wgrad_kernel(con
                 if (ci < p.Cin && co < p.Cout) dst[(long)ci * p.Cout + co] = acc[i][j][r];
             }
     }
+}
+
+template <int T>
+__global__ __launch_bounds__(256, (T == 128 ? 3 : 6)) void conv_wgrad_kernel(const WgradParams p) {
+    conv_wgrad_body<T>(p, (int)blockIdx.x);
+}
+
+// Grouped launch: the weight gradients of MANY small layers in one grid.  Everything below 32x32 pixels is a chain of
+// launches that cannot fill the chip (a 3x3 64->64 layer at 8x8 is 2560 pixels: its own launch takes ~9 us whatever the
+// split); their weight gradients are not on the critical path of the backward sweep -- only the fold at its end needs
+// them -- so the executor keeps each such layer's G tensor alive, collects the layers in a table and runs all of them
+// as one launch right before the slab fold.  Segment s owns workgroups [first_block[s], first_block[s+1]).
+struct WgradGroupSeg { WgradParams p; int first_block; int pad_; };
+__global__ __launch_bounds__(256, 6) void conv_wgrad_group_kernel(const WgradGroupSeg* segs, int nseg) {
+    int lo = 0, hi = nseg - 1;                                  // last segment whose first_block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WgradParams p = segs[lo].p;
+    conv_wgrad_body<64>(p, (int)blockIdx.x - segs[lo].first_block);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -482,7 +482,8 @@ static void free_all(dr_handle* h) {
     for (void* p : {(void*)h->flat_param, (void*)h->flat_grad, (void*)h->adam_m, (void*)h->adam_v, (void*)h->flat_state, (void*)h->flat_state_next,
                     (void*)h->shadow, (void*)h->wp, (void*)h->wpT, (void*)h->fold, (void*)h->stats, (void*)h->bnc,
                     (void*)h->act_arena, (void*)h->grad_arena, (void*)h->scratch, (void*)h->tiny, (void*)h->tiny_ext, (void*)h->zeros,
-                    (void*)h->losses, (void*)h->reg_segs, (void*)h->loss_acc, (void*)h->bn_coef, (void*)h->wg_partial, (void*)h->fold_dev, h->pack_dev, h->zero_dev})
+                    (void*)h->losses, (void*)h->reg_segs, (void*)h->loss_acc, (void*)h->bn_coef, (void*)h->wg_partial, (void*)h->fold_dev, h->pack_dev, h->zero_dev,
+                    (void*)h->g_keep_arena, (void*)h->group_dev})
         if (p) rt::dfree(p);
     for (int l = 1; l < DR_MAX_LANES; ++l) {
         if (h->scratch_l[l]) rt::dfree(h->scratch_l[l]);
@@ -603,6 +604,8 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         h->cap_stream = rt::stream_create();
         const char* fuse = getenv("DR_FUSE_BN_BWD");
         h->fuse_bn_bwd = !(fuse && fuse[0] == '0');
+        const char* grp = getenv("DR_GROUP_WGRAD");
+        h->group_wgrad = !(grp && grp[0] == '0');
     }
     for (int l = 1; l < h->n_lanes; ++l) {
         h->lane_stream[l] = rt::stream_create();
@@ -1301,7 +1304,8 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     for (void* q : tmp) ok = ok && q;
     float* wpT = nullptr;
     int KpT = 0, NpT = 0;
-    if (ok && !a->dout) {
+    const bool consumer = a->gr && a->wr && (a->kr == 1 || a->kr == 3) && a->Cr > 0;
+    if (ok && consumer) {
         KpT = dr_round_up(a->Cr, 16); NpT = dr_round_up(C, 32);
         wpT = (float*)alloc((size_t)a->kr * a->kr * KpT * NpT * 4);
         ok = ok && wpT;
@@ -1344,7 +1348,7 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     bp.scale = scale; bp.shift = shift; bp.bnc = a->bnc; bp.gamma = a->gamma;
     bp.coef = small + 4 * C; bp.dbeta = a->dbeta; bp.dgamma = a->dgamma; bp.draw = a->draw;
     if (a->res && a->dres) { bp.dres = View{a->dres, cs, 0, C}; bp.dres_acc = 0; }
-    if (!rc && a->dout) {
+    if (!rc && !consumer) {
         rt::d2d(a->dout_used, a->dout, (size_t)M * cs * 4, s);
         bp.dout = View{a->dout_used, cs, 0, C};
         bp.part = part; bp.part_rows = grid_for(M, rpb * 8, 256);
@@ -1355,6 +1359,10 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
         ConvParams q{};
         q.x = a->gr; q.x_cs = a->gr_cs; q.Cin = a->Cr; q.B = a->B; q.H = a->H; q.W = a->W; q.ksize = a->kr;
         q.w = wpT; q.Kp = KpT; q.Np = NpT; q.y = a->dout_used; q.y_cs = cs; q.Cout = C; q.zeros = zeros;
+        if (a->dout) {                  // dOut already holds another reader's contribution: this dgrad is the LAST writer
+            rt::d2d(a->dout_used, a->dout, (size_t)M * cs * 4, s);
+            q.res = a->dout_used; q.res_cs = cs; q.res_coff = 0;
+        }
         q.stat_part = part2; q.bst_raw = a->raw; q.bst_cs = cs; q.bst_relu = a->relu ? 1 : 0;
         q.bst_scale = scale; q.bst_shift = shift; q.bst_bnc = a->bnc;
         bp.dout = View{a->dout_used, cs, 0, C};
@@ -1375,6 +1383,31 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     std::string m;
     if (rc || rt::last_error(&m)) return DR_E_DEVICE;
     return DR_OK;
+}
+
+extern "C" int dr_dbg_act_dgrad(int B, int H, int W, int C, int Cr, int kr, const float* out, const float* gr, int gr_cs,
+                                const float* wr, float factor, float* g, float* dbias, dr_stream stream) {
+    if (!out || !gr || !wr || !g || !dbias || (kr != 1 && kr != 3) || C < 1 || Cr < 1) return DR_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int cs = dr_round_up(C, 4), tr = kr * kr, KpT = dr_round_up(Cr, 16), NpT = dr_round_up(C, 32);
+    const long M = (long)B * H * W;
+    float* wpT = (float*)rt::dmalloc((size_t)tr * KpT * NpT * 4);
+    float* zeros = (float*)rt::dmalloc(256);
+    double* part = (double*)rt::dmalloc((size_t)std::max<long>((M + 31) / 32, 1024) * 2 * C * 8);
+    if (!wpT || !zeros || !part) return DR_E_NOMEM;
+    rt::memset_async(zeros, 0, 256, s);
+    DR_LAUNCH(pack_weights_T_kernel, dim3(grid_for((long)tr * KpT * NpT)), dim3(256), 0, s, wr, wpT, tr, C, Cr, KpT, NpT);
+    ConvParams q{};
+    q.x = gr; q.x_cs = gr_cs; q.Cin = Cr; q.B = B; q.H = H; q.W = W; q.ksize = kr;
+    q.w = wpT; q.Kp = KpT; q.Np = NpT; q.y = g; q.y_cs = cs; q.Cout = C; q.zeros = zeros;
+    q.stat_part = part; q.bst_raw = out; q.bst_cs = cs; q.bst_relu = 1; q.bst_act = 1; q.bst_factor = factor;
+    const int rows = conv_stat_rows(q);
+    int rc = launch_conv_igemm(q, s);
+    if (!rc) DR_LAUNCH(bias_grad_from_rows_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, s, (const double*)part, rows, C, dbias);
+    rt::sync_stream(s);
+    rt::dfree(wpT); rt::dfree(zeros); rt::dfree(part);
+    std::string m;
+    return (rc || rt::last_error(&m)) ? DR_E_DEVICE : DR_OK;
 }
 
 // Micro-benchmark of the weight-gradient kernel + slab fold on self-allocated buffers: microseconds per call for a

@@ -7,6 +7,7 @@
 
 #include "../../include/densereg.h"
 #include "dr_platform.h"
+#include "conv_wgrad.h"
 #include "kernels_misc.h"
 
 namespace dr {
@@ -56,6 +57,8 @@ struct ConvLayer {
     Tensor* raw = nullptr;             // pre-BN conv output (training)
     int bst_rows = 0;                  // backward sweep: > 0 = the consumer's dgrad already wrote this many partial rows of
                                        // this layer's BatchReNorm backward sums into stat_part2 (train_exec.inc)
+    float* g_keep = nullptr;           // small layers (training): a private dRaw buffer that outlives the layer's step of the
+                                       // backward sweep, so its weight gradient can run in the grouped launch at the end
 };
 
 enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_UPADD, OP_UVD, OP_COPY, OP_FORK, OP_JOIN };
@@ -80,6 +83,7 @@ struct Op {
     TView uvd0, uvd1;                  // OP_UVD destinations
     bool ow_in = false, ow_in2 = false; // backward: this op is the FIRST writer of grad(in) / grad(in2) -> overwrite
     int bst_conv = -1;                 // backward: this conv's dgrad also reduces the BatchReNorm backward sums of conv #bst_conv
+    bool bst_last = false;             // ... as the LAST (accumulating) writer of that layer's output gradient rather than the only one
 };
 
 enum ParamKind { PK_WEIGHT, PK_BETA, PK_GAMMA, PK_BIAS, PK_MMEAN, PK_MVAR, PK_RMAX, PK_DMAX, PK_CURRT };
@@ -180,6 +184,12 @@ struct dr_handle {
     int fold_blocks = 0;
     size_t n_loss_part = 0;                                // rows of the loss kernel's partial sums (loss_acc)
     void* pack_dev = nullptr; int pack_nseg = 0, pack_blocks = 0;   // segment table of the one-launch weight packing
+    // grouped weight gradient of the small layers (conv_wgrad.h: conv_wgrad_group_kernel), single-stream executor
+    float* g_keep_arena = nullptr;                          // the layers' private dRaw buffers
+    std::vector<dr::WgradGroupSeg> group_host, group_uploaded;   // segments of the sweep in progress / what group_dev holds
+    dr::WgradGroupSeg* group_dev = nullptr;
+    int group_blocks = 0; double group_flops = 0, group_bytes = 0;
+    bool group_wgrad = true;                                // DR_GROUP_WGRAD=0: every layer launches its own weight gradient
     bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold
     const float* dm_train = nullptr;                       // input of the last dr_forward_train
 };

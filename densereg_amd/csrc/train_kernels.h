@@ -123,6 +123,16 @@ __global__ __launch_bounds__(256) void stat_fold_kernel(const double* part, int 
     if ((threadIdx.x & 63) == 0) { out[c] = sum; out[C + c] = sq; }
 }
 
+// dst[c] += sum of the first block of partial rows ([C][rows] doubles): the bias gradient of a conv whose column sums were
+// produced by its reader's dgrad epilogue (conv_igemm.h, bst_act)
+__global__ __launch_bounds__(256) void bias_grad_from_rows_kernel(const double* part, int rows, int C, float* dst) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double sum, unused;
+    fold_partials_wave(part, rows, C, c, sum, unused);
+    if ((threadIdx.x & 63) == 0) dst[c] += (float)sum;
+}
+
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const BnTrainParams p) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= p.C) return;
@@ -645,18 +655,21 @@ __global__ __launch_bounds__(256) void reg_grad_kernel(const float* param, float
 }
 // Sums the partial rows of the loss kernels in a fixed order (1168 same-address fp64 atomics cost 100 us here and made
 // the reported loss depend on their order).  loss_part = [3][n_loss] rows of loss_kernel, reg_part = n_reg partials.
-__global__ __launch_bounds__(64) void losses_out_kernel(const double* loss_part, int n_loss, const double* reg_part, int n_reg,
-                                                        float* out) {
-    const int lane = threadIdx.x;
-    for (int t = 0; t < 4; ++t) {
-        const double* src = t < 3 ? loss_part + (long)t * n_loss : reg_part;
-        const int n = t < 3 ? n_loss : n_reg;
-        double a = 0.0;
-        for (int i = lane; i < n; i += 64) a += src[i];
+__global__ __launch_bounds__(256) void losses_out_kernel(const double* loss_part, int n_loss, const double* reg_part, int n_reg,
+                                                         float* out) {
+    // one wave per loss term (the regulariser's ~9000 partials were a 146-deep chain of dependent loads on one wave: 38 us);
+    // per wave: lane-strided loads, four independent accumulators, fixed shuffle tree -- the order never depends on timing
+    const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
+    const double* src = t < 3 ? loss_part + (long)t * n_loss : reg_part;
+    const int n = t < 3 ? n_loss : n_reg;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int i = lane;
+    for (; i + 3 * 64 < n; i += 4 * 64) { a0 += src[i]; a1 += src[i + 64]; a2 += src[i + 128]; a3 += src[i + 192]; }
+    for (; i < n; i += 64) a0 += src[i];
+    double a = (a0 + a1) + (a2 + a3);
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
-        if (lane == 0) out[t] = (float)a;
-    }
+    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
+    if (lane == 0) out[t] = (float)a;
 }
 
 // ------------------------------------------------------------------------------------------------

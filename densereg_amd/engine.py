@@ -52,8 +52,10 @@ class Engine:
         self.h.close()
 
     def set_precision(self, precision: str):
-        """'f32' (default) or 'bf16': matrix-core arithmetic of the eval-mode convolutions (dr_set_precision).
-        Inference engines only; call before load_params (it un-finalizes the handle)."""
+        """'f32' (default) or 'bf16': matrix-core arithmetic of every k != 7 convolution of the handle (dr_set_precision) --
+        eval forward / infer, and on a training engine the train-mode forward, the input gradients and the weight
+        gradients; BatchReNorm, loss, Adam and the master weights stay fp32.  Call before load_params (it un-finalizes
+        the handle and the packed weights follow the precision)."""
         self.h.call('dr_set_precision', {'f32': 0, 'bf16': 1}[precision])
 
     def load_params(self, params: Dict[str, np.ndarray]):

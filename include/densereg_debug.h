@@ -37,7 +37,9 @@ int dr_dbg_bn_bench(long M, int C, int reduce_blocks, int iters, float* us_out);
  * Tensors are NHWC with channel stride cs = round_up(Cout, 4) unless a stride is given.  Backward seed: either `dout`
  * (the layer runs its own reduce pass) or a consumer convolution (`gr`, `wr`: kr x kr, Cout -> Cr): then dOut is
  * produced by that consumer's dgrad launch, which also computes the layer's backward sums in its epilogue (the
- * "single reader" path of plan_backward).  All pointers are device pointers; synchronises the stream. */
+ * "single reader" path of plan_backward); with BOTH given, `dout` is what other readers already accumulated and the
+ * consumer's dgrad adds to it as the last writer of the gradient buffer (the "last writer" path).  All pointers are
+ * device pointers; synchronises the stream. */
 typedef struct dr_dbg_bn_args {
     int B, H, W, Cin, Cout, k;
     const float* x; int x_cs;                 /* layer input */
@@ -57,6 +59,12 @@ typedef struct dr_dbg_bn_args {
     int fwd_rows, bwd_rows;                   /* out: partial rows of the two reductions (which finalize path ran) */
 } dr_dbg_bn_args;
 int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream);
+
+/* The backward of a BIAS conv with ReLU (and dropout) as its single reader's dgrad produces it (conv_igemm.h, bst_act):
+ * `out` [M][cs] is the layer's forward output, the reader is a kr x kr conv C -> Cr with output gradient `gr`; writes
+ * g [M][cs] = dOut * factor * [out > 0] (dOut = the reader's input gradient) and dbias[C] += column sums of g. */
+int dr_dbg_act_dgrad(int B, int H, int W, int C, int Cr, int kr, const float* out, const float* gr, int gr_cs, const float* wr,
+                     float factor, float* g, float* dbias, dr_stream stream);
 
 /* Micro-benchmark one conv shape on self-allocated buffers: average milliseconds per launch.
  * tile = -1 (heuristic) or a tile id (0 128x128, 1 64x128, 2 128x64, 3 64x64, 4 128x32);

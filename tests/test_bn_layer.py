@@ -46,12 +46,13 @@ def _reference(x, w, gamma, beta, mm, mv, r_max, d_max, relu, res, dout, gr, wr)
         rt_ = t(res).requires_grad_(True)
         out = out + rt_
     out.retain_grad()
+    loss = 0.0
     if dout is not None:
-        loss = (out * t(dout)).sum()
-    else:
+        loss = loss + (out * t(dout)).sum()
+    if gr is not None:
         kr = wr.shape[0]
         z = F.conv2d(out.permute(0, 3, 1, 2), t(wr).permute(3, 2, 0, 1), padding=kr // 2).permute(0, 2, 3, 1)
-        loss = (z * t(gr)).sum()
+        loss = loss + (z * t(gr)).sum()
     loss.backward()
     om = 1.0 - 0.99                                                # zero-debiased first update: biased = value*(1-decay),
     corr = 1.0 - 0.99 ** 1                                         # divided by 1 - decay^1 -> the batch value itself
@@ -62,7 +63,7 @@ def _reference(x, w, gamma, beta, mm, mv, r_max, d_max, relu, res, dout, gr, wr)
                 dout=n(out.grad), draw=n(raw.grad), dgamma=n(g_.grad), dbeta=n(b_.grad), dres=None if rt_ is None else n(rt_.grad))
 
 
-def _run(be, B, H, W, Cin, Cout, k, relu=True, with_res=False, consumer=None, seed=0, r_max=3.0, d_max=5.0):
+def _run(be, B, H, W, Cin, Cout, k, relu=True, with_res=False, consumer=None, seed=0, r_max=3.0, d_max=5.0, both=False):
     rng = np.random.default_rng(seed)
     cs, x_cs = -(-Cout // 4) * 4, -(-Cin // 4) * 4
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
@@ -74,9 +75,9 @@ def _run(be, B, H, W, Cin, Cout, k, relu=True, with_res=False, consumer=None, se
     mv = rng.uniform(0.05, 4.0, Cout).astype(np.float32)
     res = rng.standard_normal((B, H, W, Cout)).astype(np.float32) if with_res else None
     dout = gr = wr = None
-    if consumer is None:
+    if consumer is None or both:
         dout = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
-    else:
+    if consumer is not None:
         kr, Cr = consumer
         wr = (rng.standard_normal((kr, kr, Cout, Cr)) / np.sqrt(kr * kr * Cout)).astype(np.float32)
         gr = rng.standard_normal((B, H, W, Cr)).astype(np.float32)
@@ -161,6 +162,8 @@ def test_bn_layer_backward_sums_from_the_consumers_dgrad(be):
     consumers = [(1, 33), (3, 20), (1, 64)]
     for i, (B, H, W, Cin, Cout, k) in enumerate(_cases(be)):
         _run(be, B, H, W, Cin, Cout, k, relu=True, consumer=consumers[i % 3], seed=100 + i)
+        # ... and as the LAST writer: dOut already holds another reader's gradient, the dgrad accumulates onto it
+        _run(be, B, H, W, Cin, Cout, k, relu=True, with_res=(i % 2 == 1), consumer=consumers[(i + 1) % 3], seed=200 + i, both=True)
 
 
 def test_bn_layer_without_relu_and_pure_batchnorm_schedule(be):
@@ -168,3 +171,35 @@ def test_bn_layer_without_relu_and_pure_batchnorm_schedule(be):
     B, H, W, Cin, Cout, k = CASES_SMALL[0]
     _, _, clipped = _run(be, B, H, W, Cin, Cout, k, relu=False, r_max=1.0, d_max=0.0, seed=7)
     assert clipped.all()
+
+
+def test_bias_conv_backward_from_the_readers_dgrad(be):
+    """um_full 1 / 2 (bias + ReLU + dropout, um_v1.py:155-165): the single reader's dgrad writes the gradient wrt the conv's
+    pre-activation, dOut * 2 * [out > 0], and the bias column sums -- against an fp64 autograd of relu-dropout -> conv."""
+    import torch
+    import torch.nn.functional as F
+    cases = [(1, 8, 8, 70, 33, 1, 2.0), (2, 4, 4, 37, 48, 3, 1.0)]
+    if be.name == 'gpu':
+        cases += [(4, 32, 32, 512, 48, 1, 2.0), (3, 32, 32, 512, 512, 1, 2.0)]
+    for i, (B, H, W, Cc, Cr, kr, factor) in enumerate(cases):
+        rng = np.random.default_rng(50 + i)
+        cs, gr_cs = -(-Cc // 4) * 4, -(-Cr // 4) * 4
+        pre = rng.standard_normal((B, H, W, Cc))
+        keep = rng.integers(0, 2, pre.shape) if factor == 2.0 else np.ones(pre.shape)
+        out = (np.maximum(pre, 0) * keep * factor).astype(np.float32)            # what the forward stored
+        wr = (rng.standard_normal((kr, kr, Cc, Cr)) / np.sqrt(kr * kr * Cc)).astype(np.float32)
+        gr = rng.standard_normal((B, H, W, Cr)).astype(np.float32)
+        ot = torch.from_numpy(out.astype(np.float64)).requires_grad_(True)
+        z = F.conv2d(ot.permute(0, 3, 1, 2), torch.from_numpy(wr.astype(np.float64)).permute(3, 2, 0, 1), padding=kr // 2).permute(0, 2, 3, 1)
+        (z * torch.from_numpy(gr.astype(np.float64))).sum().backward()
+        g_ref = ot.grad.numpy() * factor * (out > 0)
+        pad = lambda a, stride: np.concatenate([a, np.full(a.shape[:-1] + (stride - a.shape[-1],), np.nan, np.float32)], -1)
+        d_out, d_gr, d_wr = be.dev(pad(out, cs)), be.dev(pad(gr, gr_cs)), be.dev(wr)
+        d_g, d_b = be.dev(np.full((B * H * W, cs), -777.0, np.float32)), be.dev(np.full(Cc, 0.5, np.float32))
+        rc = be.lib.dr_dbg_act_dgrad(B, H, W, Cc, Cr, kr, be.ptr(d_out), be.ptr(d_gr), gr_cs, be.ptr(d_wr), factor, be.ptr(d_g),
+                                     be.ptr(d_b), be.stream)
+        assert rc == 0, rc
+        be.sync()
+        g = be.host(d_g).reshape(B, H, W, cs)[..., :Cc]
+        assert np.abs(g - g_ref).max() / np.abs(g_ref).max() < 1e-5
+        np.testing.assert_allclose(be.host(d_b) - 0.5, g_ref.sum((0, 1, 2)), rtol=1e-5, atol=1e-5 * np.abs(g_ref).sum((0, 1, 2)).max())

@@ -22,5 +22,9 @@ def test_msra_j21_forward_vote_and_train_step_on_the_emulator(emu):
     ref = pose.estimate_pose_mm(ep['hm_outs'][-1], ep['hm3_outs'][-1], ep['um_outs'][-1], ndm, cfgs, coms)
     assert xyz.shape == (1, 63) and pose.mean_jnt_error(xyz, ref) <= 0.1
     h.close()
-    h, _ = _run_step(emu, cfg, params, ndm, poses, cfgs, coms, None)
+    # with an injected dropout mask: the um_full convs' backward (mask x2 and bias column sums) comes out of their readers'
+    # dgrad epilogues (conv_igemm.h, bst_act)
+    rng = np.random.default_rng(0)
+    masks = [rng.integers(0, 2, (1, 32, 32, 512)).astype(np.uint8) for _ in range(2)]
+    h, _ = _run_step(emu, cfg, params, ndm, poses, cfgs, coms, masks)
     h.close()

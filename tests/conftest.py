@@ -13,6 +13,12 @@ warnings.filterwarnings('ignore', message='Converting a tensor with requires_gra
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the CPU oracle: at most 32 threads (the 256-thread GPU host thrashes with torch's default of one thread per core)
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope='session')

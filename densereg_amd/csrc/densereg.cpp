@@ -483,7 +483,7 @@ static void free_all(dr_handle* h) {
                     (void*)h->shadow, (void*)h->wp, (void*)h->wpT, (void*)h->fold, (void*)h->stats, (void*)h->bnc,
                     (void*)h->act_arena, (void*)h->grad_arena, (void*)h->scratch, (void*)h->tiny, (void*)h->tiny_ext, (void*)h->zeros,
                     (void*)h->losses, (void*)h->reg_segs, (void*)h->loss_acc, (void*)h->bn_coef, (void*)h->wg_partial, (void*)h->fold_dev, h->pack_dev, h->zero_dev,
-                    (void*)h->g_keep_arena, (void*)h->group_dev})
+                    (void*)h->g_keep_arena, (void*)h->group_dev, (void*)h->bn_flags})
         if (p) rt::dfree(p);
     for (int l = 1; l < DR_MAX_LANES; ++l) {
         if (h->scratch_l[l]) rt::dfree(h->scratch_l[l]);
@@ -606,6 +606,8 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         h->fuse_bn_bwd = !(fuse && fuse[0] == '0');
         const char* grp = getenv("DR_GROUP_WGRAD");
         h->group_wgrad = !(grp && grp[0] == '0');
+        const char* lb = getenv("DR_BN_LOOKBACK");
+        h->bn_lookback = !(lb && lb[0] == '0');
     }
     for (int l = 1; l < h->n_lanes; ++l) {
         h->lane_stream[l] = rt::stream_create();
@@ -1300,6 +1302,8 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     float* small = (float*)alloc((size_t)(2 + 2 + 3) * C * 4);           // scale|shift, shadow mean|var, coef[3]
     double* part = (double*)alloc((size_t)std::max<long>((M + 31) / 32, 1024) * 2 * C * 8);
     double* part2 = (double*)alloc((size_t)std::max<long>((M + 31) / 32, 1024) * 2 * C * 8);
+    int* flags = (int*)alloc(64);
+    static const bool lookback = [] { const char* e = getenv("DR_BN_LOOKBACK"); return !(e && e[0] == '0'); }();
     bool ok = true;
     for (void* q : tmp) ok = ok && q;
     float* wpT = nullptr;
@@ -1313,6 +1317,7 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     auto cleanup = [&]() { for (void* q : tmp) if (q) rt::dfree(q); };
     if (!ok) { cleanup(); return DR_E_NOMEM; }
     rt::memset_async(zeros, 0, 256, s);
+    rt::memset_async(flags, 0, 64, s);
     rt::memset_async(small, 0, (size_t)7 * C * 4, s);
     rt::memset_async(a->dgamma, 0, (size_t)C * 4, s);
     rt::memset_async(a->dbeta, 0, (size_t)C * 4, s);
@@ -1336,10 +1341,13 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     const int rpb = 256 / (cs / 4);
     if (!rc) {
         if (fp.part_rows <= kBnFuseRows) {
-            DR_LAUNCH(bn_train_apply_kernel<true>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, fp);
+            DR_LAUNCH(bn_train_apply_kernel<1>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, fp);
+        } else if (lookback) {
+            fp.flag = flags; fp.flag_target = dr_ceil_div(C, 4);
+            DR_LAUNCH(bn_train_apply_kernel<2>, dim3(grid_for(M, rpb, 2048) + dr_ceil_div(C, 4)), dim3(256), 0, s, fp);
         } else {
             DR_LAUNCH(bn_fwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, s, fp);
-            DR_LAUNCH(bn_train_apply_kernel<false>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, fp);
+            DR_LAUNCH(bn_train_apply_kernel<0>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, fp);
         }
     }
     // ---- backward: backward_conv (BatchReNorm part) ------------------------------------------------
@@ -1372,17 +1380,35 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     a->bwd_rows = bp.part_rows;
     if (!rc) {
         if (bp.part_rows <= kBnFuseRows) {
-            DR_LAUNCH(bn_bwd_apply_kernel<true>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, bp);
+            DR_LAUNCH(bn_bwd_apply_kernel<1>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, bp);
+        } else if (lookback) {
+            bp.flag = flags + 2; bp.flag_target = dr_ceil_div(C, 4);
+            DR_LAUNCH(bn_bwd_apply_kernel<2>, dim3(grid_for(M, rpb, 2048) + dr_ceil_div(C, 4)), dim3(256), 0, s, bp);
         } else {
             DR_LAUNCH(bn_bwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, s, bp);
-            DR_LAUNCH(bn_bwd_apply_kernel<false>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, bp);
+            DR_LAUNCH(bn_bwd_apply_kernel<0>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, bp);
         }
     }
     rt::sync_stream(s);
+    int hflags[4] = {0, 0, 0, 0};
+    rt::d2h(hflags, flags, sizeof(hflags), s);
+    rt::sync_stream(s);
     cleanup();
+    if (hflags[1] || hflags[3]) return DR_E_STATE;                     // a look-back wait expired
     std::string m;
     if (rc || rt::last_error(&m)) return DR_E_DEVICE;
     return DR_OK;
+}
+
+extern "C" int dr_dbg_lookback_expired(dr_handle* h) {
+    if (!h || !h->bn_flags) return 0;
+    rt::sync_stream(nullptr);
+    std::vector<int> f(h->convs.size() * 4, 0);
+    rt::d2h(f.data(), h->bn_flags, f.size() * sizeof(int), nullptr);
+    rt::sync_stream(nullptr);
+    int n = 0;
+    for (size_t i = 0; i < h->convs.size(); ++i) n += f[4 * i + 1] + f[4 * i + 3];
+    return n;
 }
 
 extern "C" int dr_dbg_act_dgrad(int B, int H, int W, int C, int Cr, int kr, const float* out, const float* gr, int gr_cs,
@@ -1503,12 +1529,12 @@ extern "C" int dr_dbg_bn_bench(long M, int C, int reduce_blocks, int iters, floa
         auto launch = [&]() {
             if (which == 0) {
                 DR_LAUNCH(bn_fwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, (hipStream_t) nullptr, fp);
-                DR_LAUNCH(bn_train_apply_kernel<false>, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, fp);
+                DR_LAUNCH(bn_train_apply_kernel<0>, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, fp);
             } else if (which == 1) {
                 DR_LAUNCH(bn_bwd_reduce_kernel, dim3(g_reduce), dim3(256), 0, (hipStream_t) nullptr, bp);
                 DR_LAUNCH(bn_bwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, (hipStream_t) nullptr, bp);
             } else {
-                DR_LAUNCH(bn_bwd_apply_kernel<false>, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, bp);
+                DR_LAUNCH(bn_bwd_apply_kernel<0>, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, bp);
             }
         };
         for (int i = 0; i < 3; ++i) launch();

@@ -105,6 +105,19 @@ __device__ __forceinline__ void dr_glds16(const float* src, float* lds_wave_base
 }
 #endif
 
+// Cross-workgroup hand-off inside one kernel (train_kernels.h: BatchReNorm coefficient look-back): agent-scope loads that
+// bypass the non-coherent cache levels, and a polite spin.
+#if defined(DR_EMU)
+#include <sched.h>
+static inline int dr_load_agent_i32(const int* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+static inline float dr_load_agent_f32(const float* p) { float v; __atomic_load(p, &v, __ATOMIC_ACQUIRE); return v; }
+static inline void dr_spin_pause() { sched_yield(); }
+#else
+__device__ __forceinline__ int dr_load_agent_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float dr_load_agent_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void dr_spin_pause() { __builtin_amdgcn_s_sleep(2); }
+#endif
+
 typedef float dr_f32x16 __attribute__((ext_vector_type(16)));
 typedef float dr_f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 dr_bf16x8 __attribute__((ext_vector_type(8)));      // one operand of v_mfma_f32_32x32x16_bf16

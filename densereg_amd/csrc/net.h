@@ -57,6 +57,7 @@ struct ConvLayer {
     Tensor* raw = nullptr;             // pre-BN conv output (training)
     int bst_rows = 0;                  // backward sweep: > 0 = the consumer's dgrad already wrote this many partial rows of
                                        // this layer's BatchReNorm backward sums into stat_part2 (train_exec.inc)
+    int ep_fwd = 0, ep_bwd = 0;        // launches so far of the look-back apply kernels (targets of the hand-off counters)
     float* g_keep = nullptr;           // small layers (training): a private dRaw buffer that outlives the layer's step of the
                                        // backward sweep, so its weight gradient can run in the grouped launch at the end
 };
@@ -190,6 +191,9 @@ struct dr_handle {
     dr::WgradGroupSeg* group_dev = nullptr;
     int group_blocks = 0; double group_flops = 0, group_bytes = 0;
     bool group_wgrad = true;                                // DR_GROUP_WGRAD=0: every layer launches its own weight gradient
+    int* bn_flags = nullptr;                                // [2 counters + 2 expiry flags] per conv: look-back hand-off of the BatchReNorm
+                                                            // coefficients (train_kernels.h); DR_BN_LOOKBACK=0: finalize launches instead
+    bool bn_lookback = true;
     bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold
     const float* dm_train = nullptr;                       // input of the last dr_forward_train
 };

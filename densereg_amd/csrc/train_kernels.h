@@ -39,7 +39,35 @@ struct BnTrainParams {
     float* bnc;                                 // persisted [4][C]: mean, inv_std, r, d
     int relu;
     View res, out;
+    int* flag; int flag_target;                 // look-back hand-off (bn_train_apply_kernel<2>): groups published so far / wanted
 };
+
+// Look-back hand-off of per-channel coefficients inside ONE launch (replaces a separate finalize launch per layer and
+// sweep: ~200 launches of 5-6 us per training step).  The first ceil(C/4) workgroups of the grid fold the partial rows of
+// "their" four channels (one wave per channel, exactly the finalize kernel's code), write the coefficients, and publish by
+// adding to a per-layer counter; every workgroup then waits until the counter reaches its target and reads the coefficients
+// with agent-scope loads.  Forward progress: workgroups are dispatched in index order, so every producer is resident (or
+// done) before any workgroup that waits for it -- the assumption of every single-pass look-back scan.  The counter is
+// monotonic (target = launches so far x groups, kept by the host), so nothing is reset between launches.  The wait is
+// bounded: on expiry the workgroup proceeds and raises flag[1] (checked by the tests), it never hangs the device.
+constexpr int kBnSpinLimit = 1 << 22;
+__device__ __forceinline__ void bn_handoff_publish(int* flag, int groups_done) {
+    __threadfence();                                // this thread's coefficient stores: visible device-wide ...
+    __syncthreads();                                // ... for every writer of the workgroup ...
+    if (threadIdx.x == 0 && groups_done > 0) {
+        __threadfence();
+        atomicAdd(flag, groups_done);               // ... before the count says so
+    }
+}
+__device__ __forceinline__ void bn_handoff_wait(int* flag, int target) {
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while ((int)(dr_load_agent_i32(flag) - target) < 0 && ++spins < kBnSpinLimit) dr_spin_pause();
+        if (spins >= kBnSpinLimit) atomicAdd(flag + 1, 1);
+    }
+    __syncthreads();
+    __threadfence();
+}
 
 // Streaming kernels below keep kBnRows independent 16-byte loads per thread and stream in flight: hipcc does
 // not batch the loads of a "#pragma unroll"-ed grid-stride loop by itself (it waited for each one), which held
@@ -146,9 +174,32 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const BnTrainParam
 
 // FUSE: layers with few partial rows (everything at 8x8 and below) skip the finalize launch -- every workgroup
 // folds the rows itself (serially per channel, fixed order, a few L2 hits) and workgroup 0 persists the results.
-template <bool FUSE>
+// MODE 0: coefficients come from a bn_fwd_finalize_kernel launch; 1 (FUSE): few partial rows, every workgroup folds them;
+// 2: look-back hand-off (above).
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams p) {
+    constexpr bool FUSE = MODE == 1;
     __shared__ float s_sc[FUSE ? 1024 : 1], s_sh[FUSE ? 1024 : 1];
+    // MODE 2: the grid is [ceil(C/4) producer workgroups | the streaming workgroups].  A producer folds its four channels,
+    // publishes and EXITS -- it never waits, so producers cannot starve each other however few workgroups run at a time.
+    const int nprod = MODE == 2 ? (p.C + 3) >> 2 : 0;
+    if (MODE == 2) {
+        if ((int)blockIdx.x < nprod) {
+            const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+            if (c < p.C) {
+                double sum, sq;
+                fold_partials_wave(p.part, p.part_rows, p.C, c, sum, sq);
+                if ((threadIdx.x & 63) == 0) {
+                    float sc, sh;
+                    bn_channel_coeffs(p, c, sum, sq, sc, sh, true);
+                }
+            }
+            bn_handoff_publish(p.flag, 1);
+            return;
+        }
+        bn_handoff_wait(p.flag, p.flag_target);
+    }
+    const int bid = (int)blockIdx.x - nprod, nblk = (int)gridDim.x - nprod;      // this workgroup among the streaming ones
     if (FUSE) {
         for (int c = threadIdx.x; c < p.raw_cs; c += 256) {
             float sc = 0.f, sh = 0.f;
@@ -158,7 +209,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
                     sum += p.part[(long)c * p.part_rows + r];
                     sq += p.part[((long)p.C + c) * p.part_rows + r];
                 }
-                bn_channel_coeffs(p, c, sum, sq, sc, sh, blockIdx.x == 0);
+                bn_channel_coeffs(p, c, sum, sq, sc, sh, bid == 0);
             }
             s_sc[c] = sc; s_sh[c] = sh;
         }
@@ -173,7 +224,10 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
     for (int k = 0; k < 4; ++k) {
         const int c = cg * 4 + k;
         if (FUSE) { sc[k] = s_sc[c]; sh[k] = s_sh[c]; }
-        else {
+        else if (MODE == 2) {                                  // written by this launch's first workgroups
+            sc[k] = c < p.C ? dr_load_agent_f32(p.scale + c) : 0.f;
+            sh[k] = c < p.C ? dr_load_agent_f32(p.shift + c) : 0.f;
+        } else {
             sc[k] = c < p.C ? p.scale[c] : 0.f;                // written by bn_fwd_finalize_kernel
             sh[k] = c < p.C ? p.shift[c] : 0.f;
         }
@@ -181,8 +235,8 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
     const bool full = cg * 4 + 4 <= p.C;
     const bool vec_out = full && (p.out.coff % 4 == 0) && (p.out.cs % 4 == 0);
     const bool vec_res = p.res.p && full && (p.res.coff % 4 == 0) && (p.res.cs % 4 == 0);
-    const long stride = (long)gridDim.x * rpb;
-    for (long m0 = (long)blockIdx.x * rpb + rp; m0 < p.M; m0 += stride * kBnRows) {
+    const long stride = (long)nblk * rpb;
+    for (long m0 = (long)bid * rpb + rp; m0 < p.M; m0 += stride * kBnRows) {
         float4 x[kBnRows], rv[kBnRows];
 #pragma unroll
         for (int u = 0; u < kBnRows; ++u) {
@@ -242,6 +296,7 @@ struct BnBwdParams {
     float* dbeta; float* dgamma;      // flat-gradient slices (accumulated)
     float* draw;                      // out: gradient wrt the raw conv output, dense stride raw_cs
     View dres; int dres_acc;          // apply pass, nullable: residual source's gradient (+)= dOut (out = act(..) + res)
+    int* flag; int flag_target;       // look-back hand-off (bn_bwd_apply_kernel<2>)
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p) {
@@ -334,9 +389,33 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdParams 
     }
 }
 
-template <bool FUSE>      // FUSE: fold the reduce pass's rows here instead of in a finalize launch (few rows only)
+// MODE 0: coefficients from a bn_bwd_finalize_kernel launch; 1 (FUSE): fold the few partial rows here; 2: look-back hand-off
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) {
+    constexpr bool FUSE = MODE == 1;
     __shared__ float s_c[FUSE ? 3 : 1][FUSE ? 1024 : 1];
+    const int nprod = MODE == 2 ? (p.C + 3) >> 2 : 0;          // [producers | streaming workgroups], see bn_train_apply_kernel
+    if (MODE == 2) {
+        if ((int)blockIdx.x < nprod) {
+            const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+            if (c < p.C) {
+                double sg, sgy;
+                fold_partials_wave(p.part, p.part_rows, p.C, c, sg, sgy);
+                if ((threadIdx.x & 63) == 0) {
+                    const float r = p.bnc[2 * p.C + c], d = p.bnc[3 * p.C + c], istd = p.bnc[p.C + c];
+                    p.coef[0 * p.C + c] = p.gamma[c] * r * istd;
+                    p.coef[1 * p.C + c] = (float)(sg / (double)p.M);
+                    p.coef[2 * p.C + c] = (float)(sgy / (double)p.M);
+                    p.dbeta[c] += (float)sg;
+                    p.dgamma[c] += r * (float)sgy + d * (float)sg;
+                }
+            }
+            bn_handoff_publish(p.flag, 1);
+            return;
+        }
+        bn_handoff_wait(p.flag, p.flag_target);
+    }
+    const int bid = (int)blockIdx.x - nprod, nblk = (int)gridDim.x - nprod;
     if (FUSE) {
         for (int c = threadIdx.x; c < p.raw_cs; c += 256) {
             float k1 = 0.f, k2 = 0.f, k3 = 0.f;
@@ -350,7 +429,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
                 k1 = p.gamma[c] * r_ * istd_;
                 k2 = (float)(sg / (double)p.M);
                 k3 = (float)(sgy / (double)p.M);
-                if (blockIdx.x == 0) {
+                if (bid == 0) {
                     p.dbeta[c] += (float)sg;
                     p.dgamma[c] += r_ * (float)sgy + d_ * (float)sg;
                 }
@@ -371,14 +450,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
         if (c < p.C) {
             sc[k] = p.scale[c]; sh[k] = p.shift[c]; mean[k] = p.bnc[c]; istd[k] = p.bnc[p.C + c];
             if (FUSE) { c1[k] = s_c[0][c]; c2[k] = s_c[1][c]; c3[k] = s_c[2][c]; }
-            else { c1[k] = p.coef[c]; c2[k] = p.coef[p.C + c]; c3[k] = p.coef[2 * p.C + c]; }
+            else if (MODE == 2) {
+                c1[k] = dr_load_agent_f32(p.coef + c); c2[k] = dr_load_agent_f32(p.coef + p.C + c); c3[k] = dr_load_agent_f32(p.coef + 2 * p.C + c);
+            } else { c1[k] = p.coef[c]; c2[k] = p.coef[p.C + c]; c3[k] = p.coef[2 * p.C + c]; }
         }
     }
     const bool full = cg * 4 + 4 <= p.C;
     const bool vec_d = full && (p.dout.coff % 4 == 0) && (p.dout.cs % 4 == 0);
     const bool vec_r = full && p.dres.p && (p.dres.coff % 4 == 0) && (p.dres.cs % 4 == 0);
-    const long stride = (long)gridDim.x * rpb;
-    for (long m0 = (long)blockIdx.x * rpb + rp; m0 < p.M; m0 += stride * kBnRows) {
+    const long stride = (long)nblk * rpb;
+    for (long m0 = (long)bid * rpb + rp; m0 < p.M; m0 += stride * kBnRows) {
         float4 x4[kBnRows], d4[kBnRows];
 #pragma unroll
         for (int u = 0; u < kBnRows; ++u) {

@@ -66,6 +66,10 @@ int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream);
 int dr_dbg_act_dgrad(int B, int H, int W, int C, int Cr, int kr, const float* out, const float* gr, int gr_cs, const float* wr,
                      float factor, float* g, float* dbias, dr_stream stream);
 
+/* Training handles: how many look-back waits of the BatchReNorm apply kernels expired so far (train_kernels.h: the wait is
+ * bounded so that a scheduling surprise can never hang the device; it must stay 0).  Synchronises the device. */
+int dr_dbg_lookback_expired(dr_handle* h);
+
 /* Micro-benchmark one conv shape on self-allocated buffers: average milliseconds per launch.
  * tile = -1 (heuristic) or a tile id (0 128x128, 1 64x128, 2 128x64, 3 64x64, 4 128x32);
  * abl = 0 product kernel, 1/2/3 = ablations of the 128x128 kernel (no refills / no MFMA / no stores),

@@ -95,13 +95,16 @@ def _run_step(be, cfg, params, ndm, poses, cfgs, coms, masks, ref64=True):
     for name in g:
         sc = np.abs(g[name]).max() + 1e-12
         assert np.abs(g2[name] - 2.0 * g[name]).max() / sc < 1e-4, name
+    assert h.lib.dr_dbg_lookback_expired(h._h) == 0          # no look-back wait of the BatchReNorm hand-off ever ran out
     # BatchReNorm state after one micro-step (moving stats with zero-debias, r_max/d_max/curr_t schedule)
     p2 = {k: v.copy() for k, v in params.items()}
     net.bn_state_update(p2, upd, zero_debias=True, shadow={})
     got = h.read_params()
     for k in p2:
         if 'moving' in k or k.endswith(('r_max', 'd_max', 'curr_t')):
-            np.testing.assert_allclose(got[k], p2[k], rtol=2e-4, atol=5e-5, err_msg=k)
+            # atol scales with the tensor: on the deep S=4 net the batch means reach ~100 and an element near zero carries the
+            # fp32 rounding of its neighbours' magnitude
+            np.testing.assert_allclose(got[k], p2[k], rtol=2e-4, atol=5e-5 * max(1.0, float(np.abs(p2[k]).max())), err_msg=k)
     return h, g64
 
 
@@ -214,6 +217,14 @@ def test_grouped_small_layer_wgrad_matches_per_layer_launches(be, monkeypatch):
         h.close()
         return out
     grouped, single = run(True), run(False)
+    # the look-back hand-off of the BatchReNorm coefficients vs a finalize launch per layer: the same fold code; what is
+    # left between two runs is the order of the few fp atomics on the path (stem moments, max-pool backward scatter)
+    monkeypatch.setenv('DR_BN_LOOKBACK', '0')
+    no_lookback = run(True)
+    monkeypatch.delenv('DR_BN_LOOKBACK')
+    for ga, gb in zip(grouped, no_lookback):
+        for n in ga:
+            assert np.abs(ga[n] - gb[n]).max() / (np.abs(gb[n]).max() + 1e-12) < 2e-5, n
     differs = 0
     for ga, gb in zip(grouped, single):
         for n in ga:

@@ -606,8 +606,9 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         h->fuse_bn_bwd = !(fuse && fuse[0] == '0');
         const char* grp = getenv("DR_GROUP_WGRAD");
         h->group_wgrad = !(grp && grp[0] == '0');
+        // opt-in: measured slower on MI355X (train_kernels.h, bn_handoff_wait) -- BatchReNorm 5.5 -> 8.1 ms per step
         const char* lb = getenv("DR_BN_LOOKBACK");
-        h->bn_lookback = !(lb && lb[0] == '0');
+        h->bn_lookback = lb && lb[0] == '1';
     }
     for (int l = 1; l < h->n_lanes; ++l) {
         h->lane_stream[l] = rt::stream_create();
@@ -1303,7 +1304,8 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     double* part = (double*)alloc((size_t)std::max<long>((M + 31) / 32, 1024) * 2 * C * 8);
     double* part2 = (double*)alloc((size_t)std::max<long>((M + 31) / 32, 1024) * 2 * C * 8);
     int* flags = (int*)alloc(64);
-    static const bool lookback = [] { const char* e = getenv("DR_BN_LOOKBACK"); return !(e && e[0] == '0'); }();
+    const char* lb_env = getenv("DR_BN_LOOKBACK");
+    const bool lookback = lb_env && lb_env[0] == '1';
     bool ok = true;
     for (void* q : tmp) ok = ok && q;
     float* wpT = nullptr;

@@ -112,7 +112,10 @@ __device__ __forceinline__ void dr_glds16(const float* src, float* lds_wave_base
 static inline int dr_load_agent_i32(const int* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 static inline float dr_load_agent_f32(const float* p) { float v; __atomic_load(p, &v, __ATOMIC_ACQUIRE); return v; }
 static inline void dr_spin_pause() { sched_yield(); }
+static inline void dr_acquire_agent() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
 #else
+// acquire at agent scope: drops the non-coherent lines of this CU's L1 and this XCD's L2 (no write-back)
+__device__ __forceinline__ void dr_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 __device__ __forceinline__ int dr_load_agent_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float dr_load_agent_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void dr_spin_pause() { __builtin_amdgcn_s_sleep(2); }

@@ -192,8 +192,8 @@ struct dr_handle {
     int group_blocks = 0; double group_flops = 0, group_bytes = 0;
     bool group_wgrad = true;                                // DR_GROUP_WGRAD=0: every layer launches its own weight gradient
     int* bn_flags = nullptr;                                // [2 counters + 2 expiry flags] per conv: look-back hand-off of the BatchReNorm
-                                                            // coefficients (train_kernels.h); DR_BN_LOOKBACK=0: finalize launches instead
-    bool bn_lookback = true;
+                                                            // coefficients (train_kernels.h), opt-in with DR_BN_LOOKBACK=1 (measured slower)
+    bool bn_lookback = false;
     bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold
     const float* dm_train = nullptr;                       // input of the last dr_forward_train
 };

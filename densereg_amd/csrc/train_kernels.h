@@ -42,8 +42,12 @@ struct BnTrainParams {
     int* flag; int flag_target;                 // look-back hand-off (bn_train_apply_kernel<2>): groups published so far / wanted
 };
 
-// Look-back hand-off of per-channel coefficients inside ONE launch (replaces a separate finalize launch per layer and
-// sweep: ~200 launches of 5-6 us per training step).  The first ceil(C/4) workgroups of the grid fold the partial rows of
+// Look-back hand-off of per-channel coefficients inside ONE launch instead of a separate finalize launch per layer and
+// sweep (~200 launches of 5-6 us per training step).  OPT-IN (DR_BN_LOOKBACK=1) and NOT the default: measured on MI355X it
+// is slower in both forms tried -- the eight XCDs' L2s are not coherent with each other, so the consumers either read
+// every coefficient with agent-scope loads (4 M uncached loads per launch: BatchReNorm 5.5 -> 30 ms per step) or take one
+// acquire per workgroup, which drops the conv output the pass is about to stream from the L2 it still sits in
+// (5.5 -> 8.1 ms).  A kernel boundary is the cheap way to publish across XCDs on this part.  The first ceil(C/4) workgroups of the grid fold the partial rows of
 // "their" four channels (one wave per channel, exactly the finalize kernel's code), write the coefficients, and publish by
 // adding to a per-layer counter; every workgroup then waits until the counter reaches its target and reads the coefficients
 // with agent-scope loads.  Forward progress: workgroups are dispatched in index order, so every producer is resident (or
@@ -64,9 +68,13 @@ __device__ __forceinline__ void bn_handoff_wait(int* flag, int target) {
         int spins = 0;
         while ((int)(dr_load_agent_i32(flag) - target) < 0 && ++spins < kBnSpinLimit) dr_spin_pause();
         if (spins >= kBnSpinLimit) atomicAdd(flag + 1, 1);
+        // ONE acquire per workgroup, before the barrier releases the other waves: it invalidates the caches all of them read
+        // through (this CU's L1, this XCD's L2), so plain loads of the coefficients are fresh afterwards.  (A fence in every
+        // wave plus agent-scope loads of every coefficient in every thread -- 4 M uncached loads per launch -- measured 125 us
+        // per launch: five times the finalize launches this replaces.)
+        dr_acquire_agent();
     }
     __syncthreads();
-    __threadfence();
 }
 
 // Streaming kernels below keep kBnRows independent 16-byte loads per thread and stream in flight: hipcc does
@@ -224,10 +232,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
     for (int k = 0; k < 4; ++k) {
         const int c = cg * 4 + k;
         if (FUSE) { sc[k] = s_sc[c]; sh[k] = s_sh[c]; }
-        else if (MODE == 2) {                                  // written by this launch's first workgroups
-            sc[k] = c < p.C ? dr_load_agent_f32(p.scale + c) : 0.f;
-            sh[k] = c < p.C ? dr_load_agent_f32(p.shift + c) : 0.f;
-        } else {
+        else {
             sc[k] = c < p.C ? p.scale[c] : 0.f;                // written by bn_fwd_finalize_kernel
             sh[k] = c < p.C ? p.shift[c] : 0.f;
         }
@@ -450,9 +455,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
         if (c < p.C) {
             sc[k] = p.scale[c]; sh[k] = p.shift[c]; mean[k] = p.bnc[c]; istd[k] = p.bnc[p.C + c];
             if (FUSE) { c1[k] = s_c[0][c]; c2[k] = s_c[1][c]; c3[k] = s_c[2][c]; }
-            else if (MODE == 2) {
-                c1[k] = dr_load_agent_f32(p.coef + c); c2[k] = dr_load_agent_f32(p.coef + p.C + c); c3[k] = dr_load_agent_f32(p.coef + 2 * p.C + c);
-            } else { c1[k] = p.coef[c]; c2[k] = p.coef[p.C + c]; c3[k] = p.coef[2 * p.C + c]; }
+            else { c1[k] = p.coef[c]; c2[k] = p.coef[p.C + c]; c3[k] = p.coef[2 * p.C + c]; }
         }
     }
     const bool full = cg * 4 + 4 <= p.C;

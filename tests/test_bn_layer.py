@@ -203,3 +203,12 @@ def test_bias_conv_backward_from_the_readers_dgrad(be):
         g = be.host(d_g).reshape(B, H, W, cs)[..., :Cc]
         assert np.abs(g - g_ref).max() / np.abs(g_ref).max() < 1e-5
         np.testing.assert_allclose(be.host(d_b) - 0.5, g_ref.sum((0, 1, 2)), rtol=1e-5, atol=1e-5 * np.abs(g_ref).sum((0, 1, 2)).max())
+
+
+def test_bn_layer_lookback_handoff_opt_in(be, monkeypatch):
+    """DR_BN_LOOKBACK=1 (opt-in; measured slower on MI355X, kept correct): the apply launches carry producer workgroups that
+    fold the partial rows and hand the coefficients to the streaming workgroups behind a counter, no finalize launch."""
+    monkeypatch.setenv('DR_BN_LOOKBACK', '1')
+    for i, case in enumerate([(8, 32, 32, 8, 65, 1), (8, 32, 32, 16, 131, 1)] if be.name == 'emu' else [(8, 32, 32, 8, 65, 1), (40, 32, 32, 128, 256, 1)]):
+        fr, br, _ = _run(be, *case, relu=True, with_res=(i == 0), seed=300 + i)
+        assert fr > 48 and br > 48            # the many-rows path, where the hand-off replaces the finalize launch

@@ -219,10 +219,10 @@ def test_grouped_small_layer_wgrad_matches_per_layer_launches(be, monkeypatch):
     grouped, single = run(True), run(False)
     # the look-back hand-off of the BatchReNorm coefficients vs a finalize launch per layer: the same fold code; what is
     # left between two runs is the order of the few fp atomics on the path (stem moments, max-pool backward scatter)
-    monkeypatch.setenv('DR_BN_LOOKBACK', '0')
-    no_lookback = run(True)
+    monkeypatch.setenv('DR_BN_LOOKBACK', '1')             # opt-in (measured slower on MI355X), kept correct
+    lookback = run(True)
     monkeypatch.delenv('DR_BN_LOOKBACK')
-    for ga, gb in zip(grouped, no_lookback):
+    for ga, gb in zip(lookback, grouped):
         for n in ga:
             assert np.abs(ga[n] - gb[n]).max() / (np.abs(gb[n]).max() + 1e-12) < 2e-5, n
     differs = 0

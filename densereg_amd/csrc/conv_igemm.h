@@ -129,8 +129,16 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
     constexpr int SK = T::kSK;
     constexpr int CK = BF ? 32 : BK;      // input channels per K-tile
     constexpr int CS = BF ? 8 : 4;        // input channels per 16-byte LDS slot
-    __shared__ __attribute__((aligned(16))) float As[2][BM][SK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN][SK];
+    // The two pipeline stages are SEPARATE LDS objects (selected by a compile-time stage index), not one [2][..] array:
+    // hipcc's wait-count insertion tells LDS accesses apart by the alias scope the LDS lowering gives each object, and
+    // with a single array it put "s_waitcnt vmcnt(0)" between a tile's LDS-DMA (GL) and the fragment reads of the OTHER
+    // stage -- the asynchronous copy was waited for before the first MFMA it was meant to run under.
+    __shared__ __attribute__((aligned(16))) float As0[BM][SK];
+    __shared__ __attribute__((aligned(16))) float As1[BM][SK];
+    __shared__ __attribute__((aligned(16))) float Bs0[BN][SK];
+    __shared__ __attribute__((aligned(16))) float Bs1[BN][SK];
+#define DR_AS(stage) ((stage) ? As1 : As0)
+#define DR_BS(stage) ((stage) ? Bs1 : Bs0)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -226,14 +234,14 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
 #pragma unroll
             for (int i = 0; i < T::kAIters; ++i) {
                 const bool ok = ((a_taps[i] >> ld_tap) & 1u) && ld_kc + a_k4[i] * 4 < p.Cin;   // Cin % 4 == 0: whole chunks
-                dr_glds16(ok ? ld_x + ld_kc + a_off[i] : p.zeros, &As[dst][0][0] + (wave * 64 + i * T::kThreads) * 4);
+                dr_glds16(ok ? ld_x + ld_kc + a_off[i] : p.zeros, &DR_AS(dst)[0][0] + (wave * 64 + i * T::kThreads) * 4);
             }
 #pragma unroll
             for (int i = 0; i < T::kBIters; ++i) {
                 const int idx = tid + i * T::kThreads;
                 const int brow = idx >> 2, bs = (idx & 3) ^ ((brow >> 2) & 3);
                 const bool ok = brow < BN && n0 + brow < p.Np;
-                dr_glds16(ok ? ld_w + (unsigned)((n0 + brow) * BKC + bs * 4) : p.zeros, &Bs[dst][0][0] + (wave * 64 + i * T::kThreads) * 4);
+                dr_glds16(ok ? ld_w + (unsigned)((n0 + brow) * BKC + bs * 4) : p.zeros, &DR_BS(dst)[0][0] + (wave * 64 + i * T::kThreads) * 4);
             }
         }
         const bool tail = !GL && ld_kc + CK > p.Cin;                       // uniform: this chunk crosses Cin
@@ -300,15 +308,15 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
                 const dr_f32x8 f = {v.x, v.y, v.z, v.w, u.x, u.y, u.z, u.w};
                 v = __builtin_bit_cast(float4, __builtin_convertvector(f, dr_bf16x8));
             }
-            *reinterpret_cast<float4*>(&As[buf][r][k ^ T::swz(r)]) = v;          // swizzled 16-byte slot
+            *reinterpret_cast<float4*>(&DR_AS(buf)[r][k ^ T::swz(r)]) = v;          // swizzled 16-byte slot
         }
         if constexpr (BK == 16) {
-            if (b_row0 < BN) *reinterpret_cast<float4*>(&Bs[buf][b_row0][(b_k4 * 4) ^ T::swz(b_row0)]) = b_reg0;
+            if (b_row0 < BN) *reinterpret_cast<float4*>(&DR_BS(buf)[b_row0][(b_k4 * 4) ^ T::swz(b_row0)]) = b_reg0;
             if constexpr (T::kBIters > 1) {
-                if (b_row1 < BN) *reinterpret_cast<float4*>(&Bs[buf][b_row1][(b_k4 * 4) ^ T::swz(b_row1)]) = b_reg1;
+                if (b_row1 < BN) *reinterpret_cast<float4*>(&DR_BS(buf)[b_row1][(b_k4 * 4) ^ T::swz(b_row1)]) = b_reg1;
             }
         } else {
-            float* brow = &Bs[buf][b_row0][0];
+            float* brow = &DR_BS(buf)[b_row0][0];
             const int sw = T::swz(b_row0), kq = b_k4 * 4;
             *reinterpret_cast<float4*>(brow + ((0 * BKC + kq) ^ sw)) = b_fat0;
             *reinterpret_cast<float4*>(brow + ((1 * BKC + kq) ^ sw)) = b_fat1;
@@ -352,10 +360,10 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
         for (int g = 0; g < BK / 8; ++g) {
 #pragma unroll
             for (int i = 0; i < T::kTM; ++i)
-                a4[g][i] = *reinterpret_cast<const float4*>(&As[buf][wm * T::kWTM + i * 32 + li][(g * 8 + lk * 4) ^ T::swz(li)]);
+                a4[g][i] = *reinterpret_cast<const float4*>(&DR_AS(buf)[wm * T::kWTM + i * 32 + li][(g * 8 + lk * 4) ^ T::swz(li)]);
 #pragma unroll
             for (int j = 0; j < T::kTN; ++j)
-                b4[g][j] = *reinterpret_cast<const float4*>(&Bs[buf][wn * T::kWTN + j * 32 + li][(g * 8 + lk * 4) ^ T::swz(li)]);
+                b4[g][j] = *reinterpret_cast<const float4*>(&DR_BS(buf)[wn * T::kWTN + j * 32 + li][(g * 8 + lk * 4) ^ T::swz(li)]);
         }
         if constexpr (BF) {
 #pragma unroll
@@ -418,8 +426,8 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
 #include "conv_epilogue.inc"
     if (p.stat_part) {
         // wave partials -> LDS (the operand tiles are dead: the K loop ended on a barrier) -> one row per workgroup
-        double* red = reinterpret_cast<double*>(&As[0][0][0]);              // [2][WM][BN] doubles <= sizeof(As)
-        static_assert(sizeof(As) >= sizeof(double) * 2 * WM * BN, "stat scratch does not fit the A tile");
+        double* red = reinterpret_cast<double*>(&As0[0][0]);               // [2][WM][BN] doubles <= sizeof(As0)
+        static_assert(sizeof(As0) >= sizeof(double) * 2 * WM * BN, "stat scratch does not fit the A tile");
 #pragma unroll
         for (int j = 0; j < T::kTN; ++j) {
             double a = s1[j], b = s2[j];
@@ -441,6 +449,9 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
         }
     }
 }
+
+#undef DR_AS
+#undef DR_BS
 
 // Host-side launcher: picks the tile shape from (M, Cout).
 int launch_conv_igemm(const ConvParams& p, hipStream_t stream);

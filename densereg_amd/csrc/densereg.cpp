@@ -55,11 +55,12 @@ static void launch_cfg(const ConvParams& p, hipStream_t s) {
     DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF>), grid, dim3(256), 0, s, p);
 }
 
-// LDS-DMA refill variant (conv_igemm.h GL) for inputs made of whole 16-byte channel chunks: opt-in (DR_CONV_GLDS=1).
-// In isolation it is 6-8 % faster on every shape (profiles/r01_conv_microbench.md), inside the network step the
-// difference disappears (train 1720-1727 crops/s with either refill, three A/B repetitions).
+// LDS-DMA refill variant (conv_igemm.h GL) for inputs made of whole 16-byte channel chunks; DR_CONV_GLDS=0 selects the
+// register-staged refill everywhere.  Default since round 2: with the two pipeline stages as separate LDS objects the copy
+// really runs under the MFMAs (3x3 256->256 473 -> 457 us, 3x3 128->128 139 -> 129, 3x3 64->64 45 -> 42; training step
+// +0.5 %, inference +1.1 %; profiles/r02_conv_glds_ab.md).
 static bool conv_use_glds(const ConvParams& p) {
-    static const bool on = [] { const char* e = getenv("DR_CONV_GLDS"); return e && e[0] == '1'; }();
+    static const bool on = [] { const char* e = getenv("DR_CONV_GLDS"); return !(e && e[0] == '0'); }();
     return on && p.Cin % 4 == 0;
 }
 

@@ -37,6 +37,7 @@ inline float event_elapsed_ms(Event, Event) { return 0.f; }
 inline Event event_create_sync() { return Event{0}; }
 inline hipStream_t stream_create() { return (hipStream_t) nullptr; }         // the emulator runs every launch synchronously
 inline void stream_destroy(hipStream_t) {}
+inline hipStream_t stream_create_low_priority() { return (hipStream_t) nullptr; }
 inline void stream_wait_event(hipStream_t, Event) {}
 struct Graph { int dummy; };                                                  // no graphs on the emulator
 inline bool capture_begin(hipStream_t) { return false; }
@@ -78,6 +79,14 @@ inline float event_elapsed_ms(Event a, Event b) { float ms = 0.f; (void)hipEvent
 inline Event event_create_sync() { Event ev{}; (void)hipEventCreateWithFlags(&ev.e, hipEventDisableTiming); return ev; }
 inline hipStream_t stream_create() { hipStream_t s = nullptr; (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking); return s; }
 inline void stream_destroy(hipStream_t s) { if (s) (void)hipStreamDestroy(s); }
+// lowest-priority stream: its workgroups are dispatched after those of the caller's stream when both have work queued
+inline hipStream_t stream_create_low_priority() {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); return stream_create(); }
+    return s;
+}
 inline void stream_wait_event(hipStream_t s, Event ev) { (void)hipStreamWaitEvent(s, ev.e, 0); }
 // stream capture -> executable graph (the launch-bound inference path replays one graph instead of ~150 launches)
 struct Graph { hipGraphExec_t exec; };

@@ -191,6 +191,15 @@ struct dr_handle {
     dr::WgradGroupSeg* group_dev = nullptr;
     int group_blocks = 0; double group_flops = 0, group_bytes = 0;
     bool group_wgrad = true;                                // DR_GROUP_WGRAD=0: every layer launches its own weight gradient
+    // Weight gradients of the full-resolution layers on a library-owned low-priority stream (default; DR_WGRAD_STREAM=0 off): they are
+    // needed only by the slab fold at the end of the sweep, so they are queued while the sweep runs the heads of a stack and
+    // released when it enters the hourglass below -- a ~1.4 ms chain of launches too small to fill the chip.
+    struct PendingWgrad { dr::WgradParams p; int kind; int grid; };   // kind: 0 <64>, 1 <128>, 2 row kernel
+    std::vector<PendingWgrad> wg_pending;
+    hipStream_t wg_stream = nullptr;
+    dr::rt::Event wg_ready{}, wg_done{};
+    bool wgrad_stream = false, wg_side_used = false;
+    int wg_flush_every = 0;                                 // > 0: release the queue after every n-th queued layer as well (DR_WGRAD_STREAM=<n+1>)
     int* bn_flags = nullptr;                                // [2 counters + 2 expiry flags] per conv: look-back hand-off of the BatchReNorm
                                                             // coefficients (train_kernels.h), opt-in with DR_BN_LOOKBACK=1 (measured slower)
     bool bn_lookback = false;

@@ -616,6 +616,9 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         h->wgrad_stream = !(ws && (ws[0] < '1' || ws[0] > '9')) && cfg->training && !h->multi_stream;
         h->wg_flush_every = (h->wgrad_stream && ws) ? atoi(ws) - 1 : 0;
         if (h->wgrad_stream) {
+            // Measured and dropped (round 2): a CU-masked side stream (hipExtStreamCreateWithCUMask, 96-224 CUs: 31-37 ms per step
+            // against 20.6) and side launches cut to ~256-768 workgroups so that every CU keeps free slots (1854-1916 crops/s
+            // against 1918-1943 with the full-occupancy plan).
             h->wg_stream = rt::stream_create_low_priority();
             h->wg_ready = rt::event_create_sync();
             h->wg_done = rt::event_create_sync();

@@ -74,7 +74,7 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned l
     return (z >> 17) & 1ull;
 }
 
-template <int BM, int BN, int WM, int WN, int BK_ = 16>
+template <int BM, int BN, int WM, int WN, int BK_ = 16, int WK_ = 1>
 struct ConvTile {
     static constexpr int kBK = BK_;
     static constexpr int kThreads = 256;
@@ -89,7 +89,7 @@ struct ConvTile {
     static constexpr int kTN = kWTN / 32;
     static constexpr int kAIters = (BM * (kBK / 4)) / kThreads;
     static constexpr int kBIters = (BN * (kBK / 4) + kThreads - 1) / kThreads;
-    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(WM * WN * WK_ == 4, "4 waves per block");
     static_assert(kWTM % 32 == 0 && kWTN % 32 == 0, "wave tile must be made of 32x32 MFMA tiles");
     static_assert((BM * (kBK / 4)) % kThreads == 0, "A loader mapping");
 };
@@ -120,11 +120,17 @@ constexpr int conv_min_waves() { return BK_ == 64 ? 2 : (BM * BN >= 128 * 128 ? 
 // both operands, the same freedom to permute k the fp32 path uses).  Activations are converted while they are staged
 // (v_cvt_pk_bf16_f32, round to nearest even); weights arrive packed as bf16 [Kp/32][tap][Np][32] (pack_all_kernel),
 // byte for byte the fp32 tile layout, so the weight loader is unchanged.  Epilogue, masks and views are the fp32 ones.
-template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16, int GL = 0, int BF = 0>
-__global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_igemm_kernel(const ConvParams p) {
-    static_assert(GL == 0 || (BK_ == 16 && BN >= 64), "the LDS-DMA refill needs every wave's 64 lanes inside both tiles");
+// WK = 2 (narrow outputs: N = 65..96 and 129..160, tiles 64x96 and 64x160): the four waves are 2 (rows) x 2 (K halves).
+// A wave owns 32 rows x ALL BN columns (3 or 5 accumulator tiles) and the k-slots 8*wk .. 8*wk+7 of every K-tile; the two
+// halves are summed through LDS after the K loop, wave wk = 0 runs the epilogue.  These layers ran on the 128x32 tile, whose
+// 32-column blocks re-stage the A tile three or five times and leave each wave ONE accumulator chain (0.27 of the MFMA
+// roofline); here A is staged once, 640 workgroups of M = 40960 fall 2.5 per CU, and every fragment pair feeds 3 or 5 MFMAs.
+template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16, int GL = 0, int BF = 0, int WK = 1>
+__global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<BM, BN, BK_>())) void conv_igemm_kernel(const ConvParams p) {
+    static_assert(GL == 0 || (BK_ == 16 && BN >= 64 && BN % 64 == 0), "the LDS-DMA refill needs every wave's 64 lanes inside both tiles");
     static_assert(BF == 0 || (GL == 0 && BK_ == 16 && ABL == 0), "the bf16 variant exists for the register-staged 64-byte-row tile");
-    using T = ConvTile<BM, BN, WM, WN, BK_>;
+    static_assert(WK == 1 || (WK == 2 && BK_ == 16 && ABL == 0 && GL == 0), "K-split: two halves of a 16-k tile");
+    using T = ConvTile<BM, BN, WM, WN, BK_, WK>;
     constexpr int BK = T::kBK;
     constexpr int SK = T::kSK;
     constexpr int CK = BF ? 32 : BK;      // input channels per K-tile
@@ -143,7 +149,8 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WN;
+    const int wk = WK > 1 ? wave / (WM * WN) : 0;          // K half of this wave (WK = 2)
+    const int wm = (wave % (WM * WN)) / WN;
     const int wn = wave % WN;
     const int HW = p.H * p.W;
     const int M = p.B * HW;
@@ -204,11 +211,14 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
     // 128); scalars, not arrays: hipcc kept two-element arrays in scratch once the K loop was unrolled by two.
     // BK = 64: the tile is four 16-channel chunks, each a contiguous [BN][16] block of the packed weights; iteration
     // i of a thread IS chunk i (256 threads = 64 rows x 4 k4), so one row / k4 / offset serves all four.
-    static_assert(BK == 64 ? (BN == 64) : (T::kBIters <= 2), "B loader mapping");
+    static_assert(BK == 64 ? (BN == 64) : (T::kBIters <= 3), "B loader mapping");
     constexpr int BKC = 16;                                                 // packing granularity of the weights
     const int b_row0 = tid / (BKC / 4), b_row1 = (tid + T::kThreads) / (BKC / 4), b_k4 = tid % (BKC / 4);
     const bool b_ok0 = b_row0 < BN && n0 + b_row0 < p.Np;
     const bool b_ok1 = BK == 16 && T::kBIters > 1 && b_row1 < BN && n0 + b_row1 < p.Np;
+    const int b_row2 = (tid + 2 * T::kThreads) / (BKC / 4);                 // third float4 (BN = 160 only)
+    const bool b_ok2 = BK == 16 && T::kBIters > 2 && b_row2 < BN && n0 + b_row2 < p.Np;
+    const unsigned b_off2 = (unsigned)((n0 + b_row2) * BKC + b_k4 * 4);
     const unsigned b_off0 = (unsigned)((n0 + b_row0) * BKC + b_k4 * 4);     // = n0*16 + 4*tid: fully coalesced
     const unsigned b_off1 = (unsigned)((n0 + b_row1) * BKC + b_k4 * 4);
     const long w_chunk = (long)taps * p.Np * BKC;                           // floats between consecutive chunks of a tap
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
 
     float4 a_reg[T::kAIters];
     float4 a_hi[BF ? T::kAIters : 1];                                      // BF: channels 4..7 of the slot
-    float4 b_reg0, b_reg1;
+    float4 b_reg0, b_reg1, b_reg2;
     float4 b_fat0, b_fat1, b_fat2, b_fat3;                                 // BK = 64: one float4 per chunk (named: a
                                                                            // float4[4] here was promoted to LDS by hipcc)
 
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
         if constexpr (BK == 16) {
             b_reg0 = *reinterpret_cast<const float4*>(b_ok0 ? ld_w + b_off0 : p.zeros);
             if constexpr (T::kBIters > 1) b_reg1 = *reinterpret_cast<const float4*>(b_ok1 ? ld_w + b_off1 : p.zeros);
+            if constexpr (T::kBIters > 2) b_reg2 = *reinterpret_cast<const float4*>(b_ok2 ? ld_w + b_off2 : p.zeros);
         } else {
             const int left = n_chunks - ld_kc / BKC;                        // the last chunk group may be short
             const float* w0 = ld_w + b_off0;
@@ -315,6 +326,9 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
             if constexpr (T::kBIters > 1) {
                 if (b_row1 < BN) *reinterpret_cast<float4*>(&DR_BS(buf)[b_row1][(b_k4 * 4) ^ T::swz(b_row1)]) = b_reg1;
             }
+            if constexpr (T::kBIters > 2) {
+                if (b_row2 < BN) *reinterpret_cast<float4*>(&DR_BS(buf)[b_row2][(b_k4 * 4) ^ T::swz(b_row2)]) = b_reg2;
+            }
         } else {
             float* brow = &DR_BS(buf)[b_row0][0];
             const int sw = T::swz(b_row0), kq = b_k4 * 4;
@@ -355,19 +369,22 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
         const bool more = ABL != 1 && more_;
         const bool was_tail = ld_kc + CK > p.Cin;                           // of the tile being fetched now
         if (more && ABL != 5) load_tile(buf ^ 1);
-        float4 a4[BK / 8][T::kTM], b4[BK / 8][T::kTN];          // every fragment of this K-tile, read up front
+        // WK = 2: this wave multiplies only the k-slot group g = wk of the tile (the other half belongs to its partner wave)
+        constexpr int NG = BK / 8 / WK;                          // fragment groups per wave and K-tile
+        float4 a4[NG][T::kTM], b4[NG][T::kTN];                   // every fragment of this K-tile, read up front
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
+        for (int g = 0; g < NG; ++g) {
+            const int kg = WK > 1 ? wk * 8 : g * 8;              // first k of the group
 #pragma unroll
             for (int i = 0; i < T::kTM; ++i)
-                a4[g][i] = *reinterpret_cast<const float4*>(&DR_AS(buf)[wm * T::kWTM + i * 32 + li][(g * 8 + lk * 4) ^ T::swz(li)]);
+                a4[g][i] = *reinterpret_cast<const float4*>(&DR_AS(buf)[wm * T::kWTM + i * 32 + li][(kg + lk * 4) ^ T::swz(li)]);
 #pragma unroll
             for (int j = 0; j < T::kTN; ++j)
-                b4[g][j] = *reinterpret_cast<const float4*>(&DR_BS(buf)[wn * T::kWTN + j * 32 + li][(g * 8 + lk * 4) ^ T::swz(li)]);
+                b4[g][j] = *reinterpret_cast<const float4*>(&DR_BS(buf)[wn * T::kWTN + j * 32 + li][(kg + lk * 4) ^ T::swz(li)]);
         }
         if constexpr (BF) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
                 for (int i = 0; i < T::kTM; ++i)
 #pragma unroll
@@ -376,7 +393,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
                             __builtin_bit_cast(dr_bf16x8, a4[g][i]), __builtin_bit_cast(dr_bf16x8, b4[g][j]), accp[g % KACC][i][j], 0, 0, 0);
         } else {
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g)
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -415,6 +432,27 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
             for (int q = 1; q < KACC; ++q) acc[i][j] += accp[q][i][j];
         }
     if (ABL == 4 && abl_sink == 12345.678f) p.y[0] = abl_sink;
+    if constexpr (WK > 1) {
+        // sum the two K halves: tile by tile, wave wk = 1 parks an accumulator tile in LDS (the operand tiles are dead: the K
+        // loop ended on a barrier; 4 KB per wave = one stage of A for both of them), its partner adds it in a fixed order
+        static_assert(sizeof(As0) + sizeof(As1) >= WM * WN * 16 * 64 * sizeof(float) && sizeof(As0) == sizeof(As1), "K-split scratch");
+        float* park = (wave % (WM * WN)) == 0 ? &As0[0][0] : &As1[0][0];
+        static_assert(WM * WN == 2, "one parking buffer per wave pair");
+#pragma unroll
+        for (int j = 0; j < T::kTN; ++j) {
+            if (wk == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) park[r * 64 + lane] = acc[0][j][r];
+            }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][j][r] += park[r * 64 + lane];
+            }
+            __syncthreads();
+        }
+        static_assert(T::kTM == 1, "K-split tiles are one MFMA tile tall");
+    }
 
     // ---- epilogue: conv_epilogue.inc -------------------------------------------------------------
     double s1[T::kTN], s2[T::kTN];
@@ -422,26 +460,27 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, BK_>())) void conv_ige
     for (int j = 0; j < T::kTN; ++j) s1[j] = s2[j] = 0.0;
     constexpr int EP_TM = T::kTM, EP_TN = T::kTN;
     const int ep_m0 = m0 + wm * T::kWTM, ep_n0 = n0 + wn * T::kWTN;
-    const unsigned ep_rows = 0xFFFFu;
+    const unsigned ep_rows = (WK > 1 && wk != 0) ? 0u : 0xFFFFu;       // K-split: the wk = 0 wave holds the sums
 #include "conv_epilogue.inc"
     if (p.stat_part) {
         // wave partials -> LDS (the operand tiles are dead: the K loop ended on a barrier) -> one row per workgroup
-        double* red = reinterpret_cast<double*>(&As0[0][0]);               // [2][WM][BN] doubles <= sizeof(As0)
-        static_assert(sizeof(As0) >= sizeof(double) * 2 * WM * BN, "stat scratch does not fit the A tile");
+        // [2][WM][BN] doubles: in the first A stage (K-split tiles: wider than tall, in the first B stage)
+        double* red = reinterpret_cast<double*>(WK > 1 ? &Bs0[0][0] : &As0[0][0]);
+        static_assert((WK > 1 ? sizeof(Bs0) : sizeof(As0)) >= sizeof(double) * 2 * WM * BN, "stat scratch does not fit the operand tile");
 #pragma unroll
         for (int j = 0; j < T::kTN; ++j) {
             double a = s1[j], b = s2[j];
             a += __shfl_xor(a, 32);
             b += __shfl_xor(b, 32);
-            if (lk == 0) {
+            if (lk == 0 && wk == 0) {                                       // (K-split: the partner wave accumulated nothing)
                 const int col = wn * T::kWTN + j * 32 + li;
                 red[(0 * WM + wm) * BN + col] = a;
                 red[(1 * WM + wm) * BN + col] = b;
             }
         }
         __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, col = tid % BN, n = n0 + col;
+        for (int e = tid; e < 2 * BN; e += T::kThreads) {                   // (2 * BN > 256 on the 160-column tile)
+            const int which = e / BN, col = e % BN, n = n0 + col;
             double t = 0.0;
 #pragma unroll
             for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + col];

@@ -48,11 +48,11 @@ static inline int grid_for(long total, int block = 256, int cap = 256 * 8) {
 // ==============================================================================================
 namespace dr {
 
-template <int BM, int BN, int WM, int WN, int BK = 16, int GL = 0, int BF = 0>
+template <int BM, int BN, int WM, int WN, int BK = 16, int GL = 0, int BF = 0, int WK = 1>
 static void launch_cfg(const ConvParams& p, hipStream_t s) {
     const int M = p.B * p.H * p.W;
     dim3 grid(dr_ceil_div(M, BM), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, BN));
-    DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF>), grid, dim3(256), 0, s, p);
+    DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK>), grid, dim3(256), 0, s, p);
 }
 
 // LDS-DMA refill variant (conv_igemm.h GL) for inputs made of whole 16-byte channel chunks; DR_CONV_GLDS=0 selects the
@@ -93,6 +93,14 @@ int conv_tile_id(const ConvParams& p) {
         return KID_CONV_64x128;
     }
     if (ncols % 64 == 0) return (rows128 * (ncols / 64) >= 4096) ? KID_CONV_128x64 : KID_CONV_64x64;
+    // narrow outputs (N = 65..96, 129..160: the hm3 / um-head residuals and their input gradients) on grids that fill the
+    // chip: one 64-row workgroup spans all columns, its four waves split rows and K (conv_igemm.h, WK); DR_CONV_NARROW=0 off
+    static const bool narrow = [] { const char* e = getenv("DR_CONV_NARROW"); return !(e && e[0] == '0'); }();
+    // Measured (profiles/r02_conv_narrow_tiles.md): the MFMA count equals the 128x32 tile's, what the tile saves is the three-
+    // to five-fold re-staging of A -- so it wins where traffic binds: bf16 (3x3 from M = 40960 rows: 37 -> 30 us; at
+    // M = 163840 2x: 427 -> 204 us) and fp32 on very deep grids (M = 163840: +6..16 %); in fp32 at M = 40960 it loses 3-20 %.
+    const bool pays = p.bf16 ? (rows64 >= 512 && (p.ksize == 3 || rows64 >= 2048)) : rows64 >= 2048;
+    if (narrow && pays && (ncols == 96 || ncols == 160)) return ncols == 96 ? KID_CONV_64x96 : KID_CONV_64x160;
     return KID_CONV_128x32;
 }
 
@@ -101,7 +109,7 @@ int conv_stat_rows(const ConvParams& p) {
     const int M = p.B * p.H * p.W;
     const int t = conv_tile_id(p);
     if (t == KID_CONV_SPLITK) return dr_ceil_div(M, 32);
-    return dr_ceil_div(M, (t == KID_CONV_64x128 || t == KID_CONV_64x64 || t == KID_CONV_64x64_K64) ? 64 : 128);
+    return dr_ceil_div(M, (t == KID_CONV_64x128 || t == KID_CONV_64x64 || t == KID_CONV_64x64_K64 || t == KID_CONV_64x96 || t == KID_CONV_64x160) ? 64 : 128);
 }
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
@@ -125,6 +133,8 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
             case KID_CONV_128x64: launch_cfg<128, 64, 2, 2, 16, 0, 1>(p, s); break;
             case KID_CONV_64x64: launch_cfg<64, 64, 2, 2, 16, 0, 1>(p, s); break;
             case KID_CONV_128x32: launch_cfg<128, 32, 4, 1, 16, 0, 1>(p, s); break;
+            case KID_CONV_64x96: launch_cfg<64, 96, 2, 1, 16, 0, 1, 2>(p, s); break;
+            case KID_CONV_64x160: launch_cfg<64, 160, 2, 1, 16, 0, 1, 2>(p, s); break;
             default: return -1;
         }
         return 0;
@@ -139,6 +149,8 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
             if (conv_use_glds(p)) launch_cfg<64, 64, 2, 2, 16, 1>(p, s); else launch_cfg<64, 64, 2, 2>(p, s);
             break;
         case KID_CONV_64x64_K64: launch_cfg<64, 64, 2, 2, 64>(p, s); break;
+        case KID_CONV_64x96: launch_cfg<64, 96, 2, 1, 16, 0, 0, 2>(p, s); break;
+        case KID_CONV_64x160: launch_cfg<64, 160, 2, 1, 16, 0, 0, 2>(p, s); break;
         default: launch_cfg<128, 32, 4, 1>(p, s); break;
     }
     return 0;
@@ -1696,7 +1708,7 @@ extern "C" int dr_dbg_mfma_peak(int iters, int waves_per_simd, int zero_data, fl
 
 // force the conv tile choice of every following launch (-1 = heuristic); tests sweep all tile shapes with it
 extern "C" int dr_dbg_force_tile(int tile) {
-    if (tile < -1 || tile > KID_CONV_SPLITK) return DR_E_INVALID;
+    if (tile < -1 || tile > KID_CONV_64x160) return DR_E_INVALID;
     g_force_tile = tile;
     return DR_OK;
 }

@@ -57,11 +57,14 @@ def test_conv_fused_epilogue(be, case):
     np.testing.assert_allclose(st[1], (raw ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('tile', [6, 7, 8], ids=['splitk32x32', 'narrow64x96', 'narrow64x160'])
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
-def test_conv_splitk_kernel_fused_epilogue(be, case):
-    """conv_splitk_kernel (32x32 output tile, the four waves split K and reduce through LDS; conv_splitk.h) with every
-    fused epilogue feature, incl. the BatchReNorm statistics whose partial rows now come four to a workgroup.  Cases
-    with fewer K-tiles than waves (1x1, Cin = 16: one tile, three idle waves) are part of the list."""
+def test_conv_splitk_kernel_fused_epilogue(be, case, tile):
+    """The kernels whose waves split K and reduce through LDS, with every fused epilogue feature incl. the BatchReNorm
+    statistics: conv_splitk_kernel (tile 6: 32x32 output tile, four-way split; partial rows come four to a workgroup; cases
+    with fewer K-tiles than waves -- 1x1, Cin = 16 -- are part of the list) and the narrow-output tiles of conv_igemm.h (7 /
+    8: 64 rows x 96 / 160 columns, waves = 2 row halves x 2 K halves, partner sums parked in LDS; forced on every case of the
+    list, so also on outputs wider than one column block and narrower than a quarter of it)."""
     B, H, W, Cin, Cout, k = case
     rng = np.random.default_rng(hash(case) % 2**31 + 1)
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
@@ -71,7 +74,7 @@ def test_conv_splitk_kernel_fused_epilogue(be, case):
     res = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
     mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if k == 1 else None
     try:
-        assert be.lib.dr_dbg_force_tile(6) == 0
+        assert be.lib.dr_dbg_force_tile(tile) == 0
         y, st = be.conv2d(x, w, scale, shift, True, res, mask, -0.5, want_stats=True)
     finally:
         be.lib.dr_dbg_force_tile(-1)
@@ -99,12 +102,13 @@ def test_conv_golden_vectors(be):
         assert _rel(y, g['y%d' % i]) < 2e-5
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_conv_every_tile_shape(be, tile):
     """Each tile configuration of the implicit-GEMM kernel (the heuristic only exercises some per shape)."""
     rng = np.random.default_rng(tile)
-    np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32, 5: 64, 6: 32}[tile]   # 5 = 64x64 tile with the fat (BK = 64) K-tile,
-                                                                             # 6 = 32x32 tile, K split over the four waves
+    np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32, 5: 64, 6: 32, 7: 96, 8: 160}[tile]   # 5 = 64x64 tile with the fat (BK = 64) K-tile,
+                                                                             # 6 = 32x32 tile, K split over the four waves,
+                                                                             # 7 / 8 = 64x96 / 64x160, waves = 2 rows x 2 K halves
     Cout, Cin, k = np_needed - 3, 37, 3
     x = rng.standard_normal((1, 9, 15, Cin)).astype(np.float32)          # 135 rows: ragged last M tile
     w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
@@ -144,7 +148,7 @@ def test_conv_lds_dma_refill_variant(be, monkeypatch):
         outs.append(y)
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 6])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 6, 7, 8])
 def test_conv_bf16_matrix_core_variant(be, tile):
     """BF kernels (v_mfma_f32_32x32x16_bf16, conv_igemm.h): both operands rounded to bf16 as they are staged, fp32
     accumulation and epilogue.  Reference = the fp64 conv of the bf16-rounded operands, so what is left is fp32
@@ -152,7 +156,7 @@ def test_conv_bf16_matrix_core_variant(be, tile):
     half slot (37, 67, 515-like 35), a short last 32-channel K-tile, a single K-tile, row mask, residual, poison in
     the padding channels."""
     rng = np.random.default_rng(100 + tile)
-    np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32, 6: 96}[tile]
+    np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32, 6: 96, 7: 96, 8: 160}[tile]
     Cout = np_needed - 3
     try:
         assert be.lib.dr_dbg_force_tile(tile) == 0 and be.lib.dr_dbg_force_bf16(1) == 0

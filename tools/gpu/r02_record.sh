@@ -25,6 +25,8 @@ DR_WGRAD_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$G/prof_tra
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$G/prof_infer -o infer -- python $R/bench.py --mode infer --steps 10 --warmup 5 $P > $R/$G/rocprof_infer.log 2>&1
 DR_WGRAD_STREAM=0 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/$G/pmc_fetch -o fetch -- python $R/bench.py --steps 2 --warmup 1 $P > $R/$G/pmc_fetch.log 2>&1; echo "rc=$?" >> $R/$G/pmc_fetch.log
 DR_WGRAD_STREAM=0 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/$G/pmc_write -o write -- python $R/bench.py --steps 2 --warmup 1 $P > $R/$G/pmc_write.log 2>&1; echo "rc=$?" >> $R/$G/pmc_write.log
+DR_WGRAD_STREAM=0 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/$G/pmc_fetch_bf16 -o fetch -- python $R/bench.py --precision bf16 --steps 2 --warmup 1 $P > $R/$G/pmc_fetch_bf16.log 2>&1
+DR_WGRAD_STREAM=0 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/$G/pmc_write_bf16 -o write -- python $R/bench.py --precision bf16 --steps 2 --warmup 1 $P > $R/$G/pmc_write_bf16.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/$G/pmc_fetch_infer -o fetch -- python $R/bench.py --mode infer --steps 2 --warmup 1 $P > $R/$G/pmc_fetch_infer.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/$G/pmc_write_infer -o write -- python $R/bench.py --mode infer --steps 2 --warmup 1 $P > $R/$G/pmc_write_infer.log 2>&1
 cd $R

@@ -12,6 +12,10 @@ python tools/rocpd_pmc.py $G/pmc_fetch/fetch_results.db $G/pmc_write/write_resul
 python tools/rocpd_pmc.py $G/pmc_fetch_infer/fetch_results.db $G/pmc_write_infer/write_results.db > profiles/${R}_infer_pmc_traffic.md
 python tools/rocpd_pmc.py $G/pmc_fetch/fetch_results.db $G/pmc_write/write_results.db --json train profiles/pmc_traffic.json
 python tools/rocpd_pmc.py $G/pmc_fetch_infer/fetch_results.db $G/pmc_write_infer/write_results.db --json infer profiles/pmc_traffic.json
+if [ -f $G/pmc_fetch_bf16/fetch_results.db ]; then
+  python tools/rocpd_pmc.py $G/pmc_fetch_bf16/fetch_results.db $G/pmc_write_bf16/write_results.db > profiles/${R}_train_pmc_traffic_bf16.md
+  python tools/rocpd_pmc.py $G/pmc_fetch_bf16/fetch_results.db $G/pmc_write_bf16/write_results.db --json train_bf16 profiles/pmc_traffic.json
+fi
 for n in train infer msra c5_bf16 c5_f32 train_bf16 torchrun allreduce; do
   [ -s $G/${R}_bench_$n.json ] && cp $G/${R}_bench_$n.json profiles/${R}_bench_$n.json
 done

@@ -63,6 +63,8 @@ struct ConvParams {
                                            // stays the row stride of the packed weights (input gradients of a concat
                                            // buffer whose last channels have no consumer)
     int bf16;                              // w holds bf16 [Kp/32][tap][Np][32] (Kp % 32 == 0): launch the BF kernels
+    int x_bf16;                            // BF kernels only: x holds bf16 elements (x_cs / x_coff in elements, channel groups of 4
+                                           // zero-padded): a 16-byte slot is loaded as it is, no conversion while staging
 };
 
 // stateless keep bit for dropout(0.5): splitmix64 finaliser of (seed, element index)
@@ -125,8 +127,11 @@ constexpr int conv_min_waves() { return BK_ == 64 ? 2 : (BM * BN >= 128 * 128 ? 
 // halves are summed through LDS after the K loop, wave wk = 0 runs the epilogue.  These layers ran on the 128x32 tile, whose
 // 32-column blocks re-stage the A tile three or five times and leave each wave ONE accumulator chain (0.27 of the MFMA
 // roofline); here A is staged once, 640 workgroups of M = 40960 fall 2.5 per CU, and every fragment pair feeds 3 or 5 MFMAs.
-template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16, int GL = 0, int BF = 0, int WK = 1>
+// XB = 1 (BF kernels): the A operand is stored as bf16 (ConvParams::x_bf16) -- a compile-time variant, because a run-time
+// branch around the staging loads keeps hipcc from issuing them as one batch.
+template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16, int GL = 0, int BF = 0, int WK = 1, int XB = 0>
 __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<BM, BN, BK_>())) void conv_igemm_kernel(const ConvParams p) {
+    static_assert(XB == 0 || BF == 1, "bf16 storage of the A operand exists for the bf16 matrix-core kernels");
     static_assert(GL == 0 || (BK_ == 16 && BN >= 64 && BN % 64 == 0), "the LDS-DMA refill needs every wave's 64 lanes inside both tiles");
     static_assert(BF == 0 || (GL == 0 && BK_ == 16 && ABL == 0), "the bf16 variant exists for the register-staged 64-byte-row tile");
     static_assert(WK == 1 || (WK == 2 && BK_ == 16 && ABL == 0 && GL == 0), "K-split: two halves of a 16-k tile");
@@ -236,6 +241,8 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
     // to overlap.  The (channel-chunk, tap) cursor of the NEXT tile advances incrementally (no div/mod per tile).
     int ld_kc = 0, ld_dy = -pad, ld_dx = -pad, ld_tap = 0;
     const float* ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;      // wave-uniform cursors
+    long ld_xo = (long)(ld_dy * p.W + ld_dx) * p.x_cs;                    // the same shift as an element offset (bf16 sources)
+    constexpr bool xb16 = XB != 0;
     const float* ld_w = p.w;
     const bool ragged = (p.Cin & 3) != 0;                                  // uniform: Cin % 4 != 0
     int a_nv[T::kAIters];                                                  // only meaningful on ragged tiles
@@ -264,6 +271,12 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
                 const int left = p.Cin - (ld_kc + a_k4[i] * CS);
                 nv = left < 0 ? 0 : (left > CS ? CS : left);
                 ok = ok && nv > 0;
+            }
+            if constexpr (xb16) {                                           // 8 bf16 channels = one slot, as stored
+                const __bf16* sb = reinterpret_cast<const __bf16*>(p.x) + (ld_xo + ld_kc + (long)a_off[i]);
+                a_reg[i] = dr_load16_a4(ok ? reinterpret_cast<const void*>(sb) : reinterpret_cast<const void*>(p.zeros));
+                a_nv[i] = ok ? nv : CS;
+                continue;
             }
             const float* src = ok ? ld_x + ld_kc + a_off[i] : p.zeros;
             a_reg[i] = *reinterpret_cast<const float4*>(src);
@@ -294,6 +307,7 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
             ld_kc += CK;
         }
         ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;
+        ld_xo = (long)(ld_dy * p.W + ld_dx) * p.x_cs;
         if constexpr (BK == 16) ld_w += p.Np * BKC;                        // packed in exactly this order
         else ld_w = p.w + ((long)(ld_kc / BKC) * taps + ld_tap) * p.Np * BKC;
     };
@@ -307,6 +321,14 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
                 v.y = nv > 1 ? v.y : 0.f;
                 v.z = nv > 2 ? v.z : 0.f;
                 v.w = nv > 3 ? v.w : 0.f;
+            }
+            if constexpr (xb16) {
+                // stored bf16: channel groups of four are zero-padded by their producer, so only a slot whose upper half lies
+                // beyond the row's channels needs masking
+                float4 w16 = a_reg[i];
+                if (was_tail && a_nv[i] <= 4) { w16.z = 0.f; w16.w = 0.f; }
+                *reinterpret_cast<float4*>(&DR_AS(buf)[r][k ^ T::swz(r)]) = w16;
+                continue;
             }
             if constexpr (BF) {
                 float4 u = a_hi[i];

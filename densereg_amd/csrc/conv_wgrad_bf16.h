@@ -19,7 +19,7 @@
 
 namespace dr {
 
-template <int T>
+template <int T, int G16 = 0>      // G16: the g operand is stored as bf16 (WgradParams::g_bf16)
 __global__ __launch_bounds__(256, (T == 128 ? 2 : 4)) void conv_wgrad_bf16_kernel(const WgradParams p) {
     constexpr int BKP = 32;                // pixels per step = two MFMA k-steps of 16
     constexpr int WT = T / 2;              // wave tile
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256, (T == 128 ? 2 : 4)) void conv_wgrad_bf16_kerne
     const int tap_shift = is_x ? dy * p.W + dx : 0;
     const bool border = is_x && p.ksize > 1;
     const bool masked = is_x && p.rowmask != nullptr;
+    const bool src16 = G16 && !is_x;                                      // wave-uniform: a wave stages either x or g units
 
     float4 v[8];
     unsigned okbits = 0;                                                  // bit q: pixel q of the octet is real data
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256, (T == 128 ? 2 : 4)) void conv_wgrad_bf16_kerne
         ++next_step;
         okbits = 0;
         float mk[8];
+        unsigned eo[8];                                                   // element offset of (pixel, channel group) or 0
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int m = mb + q;
@@ -98,9 +100,21 @@ __global__ __launch_bounds__(256, (T == 128 ? 2 : 4)) void conv_wgrad_bf16_kerne
                 ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
             }
             const unsigned ms = ok ? (unsigned)(m + tap_shift) : 0u;
-            v[q] = *reinterpret_cast<const float4*>(ok ? src + (ms * cs + coff) : src);
+            eo[q] = ok ? ms * cs + coff : 0u;
             if (masked) mk[q] = p.rowmask[ms];
             okbits |= (ok ? 1u : 0u) << q;
+        }
+        // the eight loads of a unit as ONE batch of the same instruction (a branch between them makes hipcc wait for each):
+        // the wave-uniform "is this the bf16-stored g operand" decision is taken once, around the batch
+        if (G16 && src16) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {                                 // 4 bf16 channels = 8 bytes, kept as bit patterns
+                const float2 w2 = *reinterpret_cast<const float2*>(reinterpret_cast<const __bf16*>(src) + eo[q]);
+                v[q] = make_float4(w2.x, w2.y, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(src + eo[q]);
         }
         if (masked) {
 #pragma unroll
@@ -111,6 +125,31 @@ __global__ __launch_bounds__(256, (T == 128 ? 2 : 4)) void conv_wgrad_bf16_kerne
     auto store = [&](const int buf) __attribute__((always_inline)) {
         if (!has_unit) return;
         float (*dst)[16] = is_x ? Xt[buf] : Gt[buf];
+        if (G16 && src16) {
+            // already bf16: pixel q holds channels (0,1) in word x and (2,3) in word y; a channel's slot is its 16-bit half of
+            // eight pixels.  Pixels that are not data are zeroed first (two selects each); channels beyond Cout need nothing:
+            // a group of four is zero-padded by the producer and a group entirely beyond Cout never loads (nvc = 0).
+            unsigned wx[8], wy[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool live = (okbits >> q) & 1u;
+                wx[q] = live ? __builtin_bit_cast(unsigned, v[q].x) : 0u;
+                wy[q] = live ? __builtin_bit_cast(unsigned, v[q].y) : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned w[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const unsigned a0 = (j >> 1) ? wy[2 * h] : wx[2 * h], a1 = (j >> 1) ? wy[2 * h + 1] : wx[2 * h + 1];
+                    w[h] = dr_pack_halves(a0, a1, j & 1);
+                }
+                const int row = c4 + j;
+                *reinterpret_cast<float4*>(&dst[row][(po ^ ((row >> 2) & 3)) * 4]) =
+                    make_float4(__builtin_bit_cast(float, w[0]), __builtin_bit_cast(float, w[1]), __builtin_bit_cast(float, w[2]), __builtin_bit_cast(float, w[3]));
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             dr_f32x8 f;

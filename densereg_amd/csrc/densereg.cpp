@@ -52,7 +52,10 @@ template <int BM, int BN, int WM, int WN, int BK = 16, int GL = 0, int BF = 0, i
 static void launch_cfg(const ConvParams& p, hipStream_t s) {
     const int M = p.B * p.H * p.W;
     dim3 grid(dr_ceil_div(M, BM), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, BN));
-    DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK>), grid, dim3(256), 0, s, p);
+    if constexpr (BF == 1) {
+        if (p.x_bf16) { DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK, 1>), grid, dim3(256), 0, s, p); return; }
+    }
+    DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK, 0>), grid, dim3(256), 0, s, p);
 }
 
 // LDS-DMA refill variant (conv_igemm.h GL) for inputs made of whole 16-byte channel chunks; DR_CONV_GLDS=0 selects the
@@ -66,6 +69,7 @@ static bool conv_use_glds(const ConvParams& p) {
 
 static int g_force_tile = -1;        // test/bench hook (dr_dbg_conv_bench); -1 = heuristic
 static int g_dbg_bf16 = 0;           // test/bench hook (dr_dbg_force_bf16): dr_dbg_conv2d / dr_dbg_conv_bench run the bf16 kernels
+static int g_dbg_bf16_storage = 0;   // test hook (dr_dbg_force_bf16_storage): bf16-stored x / g / draw in the debug entries
 
 // tile shape for a problem (shared by the launcher and the profiler labels)
 int conv_tile_id(const ConvParams& p) {
@@ -120,6 +124,7 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     if (M * widest >= (1ll << 32)) return -1;
     if (conv_tile_id(p) == KID_CONV_SPLITK) {
         if (p.bf16 && p.Kp % 32) return -1;
+        if (p.x_bf16) return -1;                                          // the split-K kernel stages fp32 only
         dim3 grid(dr_ceil_div((int)M, 32), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, 32));
         if (p.bf16) DR_LAUNCH((conv_splitk_kernel<1>), grid, dim3(256), 0, s, p);
         else DR_LAUNCH((conv_splitk_kernel<0>), grid, dim3(256), 0, s, p);
@@ -635,6 +640,8 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
             h->wg_ready = rt::event_create_sync();
             h->wg_done = rt::event_create_sync();
         }
+        const char* b16 = getenv("DR_BF16_DRAW");
+        h->bf16_draw = !(b16 && b16[0] == '0');
         const char* lb = getenv("DR_BN_LOOKBACK");
         h->bn_lookback = lb && lb[0] == '1';
     }
@@ -1257,6 +1264,7 @@ extern "C" int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, cons
     else DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, w, wp, taps, Cin, Cout, Kp, Np);
     ConvParams p{};
     p.bf16 = g_dbg_bf16;
+    p.x_bf16 = (g_dbg_bf16 && g_dbg_bf16_storage) ? 1 : 0;
     p.x = x; p.x_cs = x_cs; p.x_coff = 0; p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.ksize = k;
     p.w = wp; p.Kp = Kp; p.Np = Np; p.y = y; p.y_cs = y_cs; p.y_coff = 0; p.Cout = Cout;
     p.scale = scale; p.shift = shift; p.relu = relu; p.res = res; p.res_cs = res_cs; p.res_coff = 0;
@@ -1300,9 +1308,10 @@ extern "C" int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const
     p.x = x; p.x_cs = x_cs; p.Cin = Cin; p.g = g; p.g_cs = g_cs; p.Cout = Cout;
     p.B = B; p.H = H; p.W = W; p.ksize = k; p.rowmask = rowmask; p.mask_thresh = thresh;
     p.partial = partial; p.nsplit = nsplit; p.rows_per_split = rows;
+    p.g_bf16 = (g_dbg_bf16 && g_dbg_bf16_storage) ? 1 : 0;
     dim3 grid(dr_ceil_div(Cin, T) * dr_ceil_div(Cout, T) * taps * nsplit);
-    if (g_dbg_bf16 && T == 128) DR_LAUNCH((conv_wgrad_bf16_kernel<128>), grid, dim3(256), 0, s, p);
-    else if (g_dbg_bf16 && T == 64) DR_LAUNCH((conv_wgrad_bf16_kernel<64>), grid, dim3(256), 0, s, p);
+    if (g_dbg_bf16 && T == 128) launch_wgrad_bf16(p, 128, grid, s);
+    else if (g_dbg_bf16 && T == 64) launch_wgrad_bf16(p, 64, grid, s);
     else if (T == 96) DR_LAUNCH(conv_wgrad_row_kernel, dim3(3 * nsplit), dim3(256), 0, s, p);
     else if (T == 128) DR_LAUNCH((conv_wgrad_kernel<128>), grid, dim3(256), 0, s, p);
     else DR_LAUNCH((conv_wgrad_kernel<64>), grid, dim3(256), 0, s, p);
@@ -1385,6 +1394,7 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     bp.raw = a->raw; bp.raw_cs = cs; bp.M = M; bp.C = C; bp.relu = a->relu ? 1 : 0;
     bp.scale = scale; bp.shift = shift; bp.bnc = a->bnc; bp.gamma = a->gamma;
     bp.coef = small + 4 * C; bp.dbeta = a->dbeta; bp.dgamma = a->dgamma; bp.draw = a->draw;
+    bp.draw_bf16 = g_dbg_bf16_storage ? 1 : 0;
     if (a->res && a->dres) { bp.dres = View{a->dres, cs, 0, C}; bp.dres_acc = 0; }
     if (!rc && !consumer) {
         rt::d2d(a->dout_used, a->dout, (size_t)M * cs * 4, s);
@@ -1714,6 +1724,11 @@ extern "C" int dr_dbg_force_tile(int tile) {
 }
 
 // dr_dbg_conv2d and dr_dbg_conv_bench (abl 0) run the bf16 matrix-core kernels while on (process-global)
+extern "C" int dr_dbg_force_bf16_storage(int on) {
+    g_dbg_bf16_storage = on ? 1 : 0;
+    return DR_OK;
+}
+
 extern "C" int dr_dbg_force_bf16(int on) {
     g_dbg_bf16 = on ? 1 : 0;
     return DR_OK;

@@ -130,9 +130,24 @@ __device__ __forceinline__ float dr_load_agent_f32(const float* p) { return __hi
 __device__ __forceinline__ void dr_spin_pause() { __builtin_amdgcn_s_sleep(2); }
 #endif
 
+// two 16-bit halves of two words in one instruction: {lo16(a), lo16(b)} (odd = 0) or {hi16(a), hi16(b)} (odd = 1), a in the
+// low half of the result (v_perm_b32)
+#if defined(DR_EMU)
+static inline unsigned dr_pack_halves(unsigned a, unsigned b, int odd) { return odd ? ((a >> 16) | (b & 0xFFFF0000u)) : ((a & 0xFFFFu) | (b << 16)); }
+#else
+__device__ __forceinline__ unsigned dr_pack_halves(unsigned a, unsigned b, int odd) {
+    return odd ? __builtin_amdgcn_perm(b, a, 0x07060302u) : __builtin_amdgcn_perm(b, a, 0x05040100u);
+}
+#endif
+
+// 16-byte load from an address that is only 4- / 8-byte aligned (rows of bf16 tensors: the row stride is a multiple of four
+// ELEMENTS): one global_load_dwordx4 on gfx950 (dword alignment is all it needs), a plain memcpy on the host emulator
+__host__ __device__ static inline float4 dr_load16_a4(const void* p) { float4 v; __builtin_memcpy(&v, p, 16); return v; }
+
 typedef float dr_f32x16 __attribute__((ext_vector_type(16)));
 typedef float dr_f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 dr_bf16x8 __attribute__((ext_vector_type(8)));      // one operand of v_mfma_f32_32x32x16_bf16
+typedef __bf16 dr_bf16x4 __attribute__((ext_vector_type(4)));
 typedef float dr_f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ static inline int dr_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -204,6 +204,7 @@ struct dr_handle {
     int* bn_flags = nullptr;                                // [2 counters + 2 expiry flags] per conv: look-back hand-off of the BatchReNorm
                                                             // coefficients (train_kernels.h), opt-in with DR_BN_LOOKBACK=1 (measured slower)
     bool bn_lookback = false;
+    bool bf16_draw = true;                                  // DR_BF16_DRAW=0: dRaw stays fp32 on the bf16 matrix-core path (train_exec.inc)
     bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold
     const float* dm_train = nullptr;                       // input of the last dr_forward_train
 };

@@ -302,6 +302,9 @@ struct BnBwdParams {
     float* draw;                      // out: gradient wrt the raw conv output, dense stride raw_cs
     View dres; int dres_acc;          // apply pass, nullable: residual source's gradient (+)= dOut (out = act(..) + res)
     int* flag; int flag_target;       // look-back hand-off (bn_bwd_apply_kernel<2>)
+    int draw_bf16;                    // draw holds bf16 elements (same element stride raw_cs): both of its readers -- the layer's
+                                      // dgrad and weight gradient on the bf16 matrix cores -- round it to bf16 anyway
+                                      // while staging, so the numbers are the same and the tensor is half the bytes
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p) {
@@ -509,7 +512,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
                 const float yh = (x[k] - mean[k]) * istd[k];
                 o[k] = (cg * 4 + k < p.C) ? c1[k] * (g[k] - c2[k] - yh * c3[k]) : 0.f;
             }
-            *reinterpret_cast<float4*>(p.draw + m * p.raw_cs + cg * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            if (p.draw_bf16) {
+                const dr_f32x4 f = {o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<dr_bf16x4*>(reinterpret_cast<__bf16*>(p.draw) + m * p.raw_cs + cg * 4) = __builtin_convertvector(f, dr_bf16x4);
+            } else {
+                *reinterpret_cast<float4*>(p.draw + m * p.raw_cs + cg * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
         }
     }
 }

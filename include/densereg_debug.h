@@ -85,6 +85,11 @@ int dr_dbg_mfma_peak(int iters, int waves_per_simd, int zero_data, float* tflops
  * bf16 matrix-core variant of the tile (dr_set_precision(DR_PREC_BF16) on a handle). */
 int dr_dbg_force_bf16(int on);
 
+/* While on (process-global, with dr_dbg_force_bf16(1)): the bf16-STORAGE variants of the bf16 matrix-core kernels --
+ * dr_dbg_conv2d reads x as bf16 elements (x_cs = element stride), dr_dbg_wgrad reads g as bf16 elements, dr_dbg_bn_layer
+ * writes draw as bf16 elements (the executor stores a BatchReNorm layer's dRaw that way on the bf16 path). */
+int dr_dbg_force_bf16_storage(int on);
+
 /* Force the conv tile of every following launch (-1 = heuristic; ids as in dr_dbg_conv_bench).
  * Process-global; tests use it to check every tile shape against the reference. */
 int dr_dbg_force_tile(int tile);

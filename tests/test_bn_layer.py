@@ -63,7 +63,8 @@ def _reference(x, w, gamma, beta, mm, mv, r_max, d_max, relu, res, dout, gr, wr)
                 dout=n(out.grad), draw=n(raw.grad), dgamma=n(g_.grad), dbeta=n(b_.grad), dres=None if rt_ is None else n(rt_.grad))
 
 
-def _run(be, B, H, W, Cin, Cout, k, relu=True, with_res=False, consumer=None, seed=0, r_max=3.0, d_max=5.0, both=False):
+def _run(be, B, H, W, Cin, Cout, k, relu=True, with_res=False, consumer=None, seed=0, r_max=3.0, d_max=5.0, both=False,
+         return_raw_draw=False):
     rng = np.random.default_rng(seed)
     cs, x_cs = -(-Cout // 4) * 4, -(-Cin // 4) * 4
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
@@ -109,6 +110,8 @@ def _run(be, B, H, W, Cin, Cout, k, relu=True, with_res=False, consumer=None, se
     rc = be.lib.dr_dbg_bn_layer(C.byref(a), be.stream)
     assert rc == 0, rc
     be.sync()
+    if return_raw_draw:                       # the draw buffer as the kernel left it (bf16-storage check of the training tests)
+        return be.host(o['draw']).reshape(M, cs).copy()
     ref = _reference(x, w, gamma, beta, mm, mv, r_max, d_max, relu, res, dout, gr, wr)
     got = {n: be.host(v).reshape(B, H, W, cs)[..., :Cout] for n, v in o.items()}
     gv = {n: be.host(v) for n, v in ov.items()}

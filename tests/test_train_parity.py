@@ -242,6 +242,88 @@ def test_grouped_small_layer_wgrad_matches_per_layer_launches(be, monkeypatch):
     assert differs > 0                    # other slab cuts = another summation order: the grouped path really ran
 
 
+def test_bf16_draw_storage_is_numerically_transparent(be):
+    """On the bf16 matrix-core path the gradient wrt a BatchReNorm layer's raw output is STORED as bf16 (half the bytes in
+    three passes): its only readers, the layer's input-gradient conv and its weight gradient, round it to bf16 while staging
+    anyway.  Checked kernel by kernel, bit for bit (the whole-network gradients cannot say it: two identical bf16 runs already
+    differ by ~1e-3 through the order of the fp atomics in the stem moments): (1) the BatchReNorm backward apply writes exactly
+    the nearest-even bf16 of what it writes in fp32; (2) the conv kernels, every tile incl. ragged channel counts whose last
+    16-byte slot hangs over the row, and (3) the weight-gradient kernel give identical results from bf16-stored and
+    fp32-stored operands of the same values."""
+    import ctypes as Cc
+    import torch
+    from densereg_amd import _lib
+    from tests.common import bf16_round
+    from tests.test_bn_layer import _run as bn_run
+    rng = np.random.default_rng(5)
+
+    def to_bf16_bits(a):                                   # fp32 array of bf16-representable values -> uint16 bit patterns
+        return (np.ascontiguousarray(a, np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    lib = be.lib
+    try:
+        assert lib.dr_dbg_force_bf16(1) == 0
+        # ---- (2) conv: x stored as bf16 vs the same values stored as fp32
+        for tile in (1, 3, 4, 7, 8):
+            for (cin, cout, k, hw) in ((36, 61, 3, (6, 5)), (65, 93, 1, (4, 7)), (16, 30, 3, (5, 5)), (140, 150, 1, (3, 4))):
+                B = 2
+                x = bf16_round(rng.standard_normal((B,) + hw + (cin,)).astype(np.float32))
+                w = (rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+                x_cs = -(-cin // 4) * 4
+                xp = np.zeros((B,) + hw + (x_cs,), np.float32)      # channel groups of four are zero-padded by the producer
+                xp[..., :cin] = x
+                outs = []
+                for stored in (0, 1):
+                    assert lib.dr_dbg_force_bf16_storage(stored) == 0 and lib.dr_dbg_force_tile(tile) == 0
+                    xin = np.concatenate([to_bf16_bits(xp).reshape(-1), np.full(64, 0x7FC0, np.uint16)]) if stored else xp   # NaN after the tensor
+                    d_x, d_w = be.dev(xin), be.dev(w)
+                    d_y = be.dev(np.zeros((B,) + hw + (cout,), np.float32))
+                    rc = lib.dr_dbg_conv2d(B, hw[0], hw[1], cin, cout, k, be.ptr(d_x), x_cs, be.ptr(d_w), None, None, 0, None, 0, None, 0.0,
+                                           be.ptr(d_y), cout, None, be.stream)
+                    assert rc == 0, rc
+                    be.sync()
+                    outs.append(be.host(d_y).copy())
+                np.testing.assert_array_equal(outs[0], outs[1], err_msg='conv tile %d %s' % (tile, (cin, cout, k)))
+        lib.dr_dbg_force_tile(-1)
+        # ---- (3) weight gradient: g stored as bf16
+        for (cin, cout, k, hw, T) in ((40, 61, 3, (6, 6), 64), (130, 70, 1, (5, 8), 128), (64, 36, 3, (4, 4), 64)):
+            B = 2
+            x = rng.standard_normal((B,) + hw + (cin,)).astype(np.float32)
+            g = bf16_round(rng.standard_normal((B,) + hw + (cout,)).astype(np.float32))
+            x_cs, g_cs = -(-cin // 4) * 4, -(-cout // 4) * 4
+            xp = np.zeros((B,) + hw + (x_cs,), np.float32); xp[..., :cin] = x
+            gp = np.zeros((B,) + hw + (g_cs,), np.float32); gp[..., :cout] = g
+            outs = []
+            for stored in (0, 1):
+                assert lib.dr_dbg_force_bf16_storage(stored) == 0
+                gin = np.concatenate([to_bf16_bits(gp).reshape(-1), np.full(64, 0x7FC0, np.uint16)]) if stored else gp
+                d_x, d_g = be.dev(xp), be.dev(gin)
+                d_w = be.dev(np.zeros((k, k, cin, cout), np.float32))
+                rc = lib.dr_dbg_wgrad(B, hw[0], hw[1], cin, cout, k, be.ptr(d_x), x_cs, be.ptr(d_g), g_cs, None, 0.0, T, 3, be.ptr(d_w), be.stream)
+                assert rc == 0, rc
+                be.sync()
+                outs.append(be.host(d_w).copy())
+            np.testing.assert_array_equal(outs[0], outs[1], err_msg='wgrad %s' % ((cin, cout, k),))
+    finally:
+        lib.dr_dbg_force_bf16_storage(0)
+        lib.dr_dbg_force_bf16(0)
+        lib.dr_dbg_force_tile(-1)
+    # ---- (1) BatchReNorm backward apply: bf16 draw == RNE(fp32 draw)
+    for case in ((2, 4, 4, 19, 65, 1), (8, 32, 32, 8, 78, 1)):
+        draws = []
+        for stored in (0, 1):
+            lib.dr_dbg_force_bf16_storage(stored)
+            try:
+                d = bn_run(be, *case, relu=True, with_res=True, seed=9, return_raw_draw=True)
+            finally:
+                lib.dr_dbg_force_bf16_storage(0)
+            draws.append(d)
+        M, cs, Cout = draws[0].shape[0], draws[0].shape[1], case[4]
+        want = bf16_round(draws[0][:, :Cout])
+        bits = np.ascontiguousarray(draws[1]).view(np.uint16).reshape(-1)[:M * cs].reshape(M, cs)[:, :Cout]
+        got = (bits.astype(np.uint32) << 16).view(np.float32)
+        np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.gpu
 def test_train_step_config3_nyu_two_stacks_dropout_mask(gpu):
     """BASELINE.json config 3 shape (NYU S=2 F=128 J=14) at B=4 with an injected dropout mask."""

@@ -9,6 +9,7 @@
 #include "conv_splitk.h"
 #include "conv_wgrad.h"
 #include "conv_wgrad_bf16.h"
+#include "conv_wgrad_tr.h"
 #include "frontend.h"
 #include "dataio.h"
 #include "kernels_misc.h"

@@ -140,6 +140,28 @@ __device__ __forceinline__ unsigned dr_pack_halves(unsigned a, unsigned b, int o
 }
 #endif
 
+// LDS transpose read (gfx950 ds_read_b64_tr_b16): within each group of 16 lanes, lane i SUPPLIES the address of a 4-element
+// (8-byte) chunk and lane c RECEIVES element (c & 3) of the chunks of lanes 4j + (c >> 2), j = 0..3 -- with the chunks laid
+// out as a [4 k][16 columns] block (chunk i = k i/4, columns 4(i%4)..+3; any row stride) lane c gets the four k of column c:
+// an MFMA operand fragment straight out of a row-major image.  Returned as two words: {e0 | e1 << 16, e2 | e3 << 16}.
+#if defined(DR_EMU)
+static inline uint2 dr_lds_read_tr16(const void* chunk) {
+    unsigned short e[4];
+    const int l = hipemu::lane_id(), gb = l & ~15, c = l & 15;
+    for (int j = 0; j < 4; ++j) {
+        const uintptr_t a = hipemu::exchange((uintptr_t)chunk, gb + 4 * j + (c >> 2));
+        e[j] = reinterpret_cast<const unsigned short*>(a)[c & 3];
+    }
+    return make_uint2((unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16));
+}
+#else
+typedef short dr_i16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 dr_lds_read_tr16(const void* chunk) {
+    const dr_i16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dr_i16x4*)chunk);
+    return __builtin_bit_cast(uint2, r);
+}
+#endif
+
 // 16-byte load from an address that is only 4- / 8-byte aligned (rows of bf16 tensors: the row stride is a multiple of four
 // ELEMENTS): one global_load_dwordx4 on gfx950 (dword alignment is all it needs), a plain memcpy on the host emulator
 __host__ __device__ static inline float4 dr_load16_a4(const void* p) { float4 v; __builtin_memcpy(&v, p, 16); return v; }

@@ -36,6 +36,8 @@ struct dim3 {
     constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct float2 { float x, y; };
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 struct alignas(16) float4 { float x, y, z, w; };
 struct int2 { int x, y; };
 struct alignas(16) int4 { int x, y, z, w; };

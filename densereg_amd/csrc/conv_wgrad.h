@@ -23,6 +23,7 @@ struct WgradParams {
     const float* rowmask; float mask_thresh;     // forward-input rows that were read as zero
     float* partial;                              // [nsplit][taps][Cin][Cout]
     int nsplit; int rows_per_split;              // multiple of 16
+    int x_bf16;                                  // conv_wgrad_tr_kernel only: x holds bf16 elements (BnTrainParams::out_bf16)
     int g_bf16;                                  // conv_wgrad_bf16_kernel only: g holds bf16 elements (stride g_cs elements, channel
                                                  // groups of four zero-padded) -- see BnBwdParams::draw_bf16
 };

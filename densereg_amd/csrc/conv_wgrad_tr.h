@@ -16,7 +16,7 @@
 
 namespace dr {
 
-template <int T, int G16>
+template <int T, int G16, int X16 = 0>      // G16 / X16: the g / x operand is stored as bf16
 __global__ __launch_bounds__(256, (T == 128 ? 2 : 4)) void conv_wgrad_tr_kernel(const WgradParams p) {
     constexpr int BKP = 32;                // pixels per step = two MFMA k-steps of 16
     constexpr int WT = T / 2;              // wave tile
@@ -108,8 +108,12 @@ __global__ __launch_bounds__(256, (T == 128 ? 2 : 4)) void conv_wgrad_tr_kernel(
         // an fp32 chunk is only fetched where the row has it (a chunk of <= 4 valid channels ends at the row's last 16 bytes)
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
-            xa[i] = *reinterpret_cast<const float4*>(p.x + xo[i]);
-            xb[i] = *reinterpret_cast<const float4*>(p.x + (x_nv[i] > 4 ? xo[i] + 4u : xo[i]));
+            if constexpr (X16) {
+                xa[i] = dr_load16_a4(reinterpret_cast<const __bf16*>(p.x) + xo[i]);
+            } else {
+                xa[i] = *reinterpret_cast<const float4*>(p.x + xo[i]);
+                xb[i] = *reinterpret_cast<const float4*>(p.x + (x_nv[i] > 4 ? xo[i] + 4u : xo[i]));
+            }
             if constexpr (G16) {
                 ga[i] = dr_load16_a4(reinterpret_cast<const __bf16*>(p.g) + go[i]);
             } else {
@@ -133,7 +137,15 @@ __global__ __launch_bounds__(256, (T == 128 ? 2 : 4)) void conv_wgrad_tr_kernel(
     auto store = [&](const int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
-            *reinterpret_cast<float4*>(&DR_XS(buf)[c_pix[i]][c_ch[i]]) = pack(xa[i], xb[i], x_nv[i], (x_ok >> i) & 1u);
+            if constexpr (X16) {
+                float4 w16 = xa[i];
+                const bool live = (x_ok >> i) & 1u;
+                if (!live) w16 = make_float4(0.f, 0.f, 0.f, 0.f);
+                else if (x_nv[i] <= 4) { w16.z = 0.f; w16.w = 0.f; }
+                *reinterpret_cast<float4*>(&DR_XS(buf)[c_pix[i]][c_ch[i]]) = w16;
+            } else {
+                *reinterpret_cast<float4*>(&DR_XS(buf)[c_pix[i]][c_ch[i]]) = pack(xa[i], xb[i], x_nv[i], (x_ok >> i) & 1u);
+            }
             if constexpr (G16) {
                 // stored bf16: groups of four channels are zero-padded by the producer; a chunk whose upper half hangs over the
                 // row (nv <= 4) or that is dead needs masking

@@ -641,6 +641,8 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
             h->wg_ready = rt::event_create_sync();
             h->wg_done = rt::event_create_sync();
         }
+        const char* a16 = getenv("DR_BF16_ACT");
+        h->bf16_act = !(a16 && a16[0] == '0');
         const char* b16 = getenv("DR_BF16_DRAW");
         h->bf16_draw = !(b16 && b16[0] == '0');
         const char* lb = getenv("DR_BN_LOOKBACK");
@@ -1091,6 +1093,7 @@ static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s
     if (B < 1 || B > h->cfg.max_batch) DR_FAIL(h, DR_E_INVALID, "batch %d outside [1, max_batch=%d]", B, h->cfg.max_batch);
     DR_ENTER(h);
     h->dm_in = dm;
+    for (auto& t : h->tensors) t->is_bf16 = false;          // every conv epilogue of this pass writes fp32
     if (!h->fold_is_eval) {          // a training forward overwrote the per-layer scale/shift
         int rc = fold_bn(h, s);
         if (rc) return rc;
@@ -1232,6 +1235,7 @@ int dr_read_activation(dr_handle* h, const char* scope, int B, float* host, size
         const size_t need = (size_t)M * op.out.C;
         if (count != need) DR_FAIL(h, DR_E_INVALID, "dr_read_activation: %s has %zu elements, got %zu", scope, need, count);
         if (need > h->n_scratch) DR_FAIL(h, DR_E_STATE, "scratch too small");
+        if (t->is_bf16) DR_FAIL(h, DR_E_STATE, "dr_read_activation: '%s' is stored as bf16 by the training forward on the bf16 path (DR_BF16_ACT=0 keeps fp32)", scope);
         DR_LAUNCH(copy_channels_kernel, dim3(grid_for(M * op.out.C)), dim3(256), 0, (hipStream_t) nullptr, (const float*)t->p,
                   t->cs, op.out.coff, h->scratch, op.out.C, 0, M, op.out.C, 0);
         rt::sync_stream(nullptr);
@@ -1310,6 +1314,7 @@ extern "C" int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const
     p.B = B; p.H = H; p.W = W; p.ksize = k; p.rowmask = rowmask; p.mask_thresh = thresh;
     p.partial = partial; p.nsplit = nsplit; p.rows_per_split = rows;
     p.g_bf16 = (g_dbg_bf16 && g_dbg_bf16_storage) ? 1 : 0;
+    p.x_bf16 = p.g_bf16;
     dim3 grid(dr_ceil_div(Cin, T) * dr_ceil_div(Cout, T) * taps * nsplit);
     if (g_dbg_bf16 && T == 128) launch_wgrad_bf16(p, 128, grid, s);
     else if (g_dbg_bf16 && T == 64) launch_wgrad_bf16(p, 64, grid, s);
@@ -1378,6 +1383,7 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     fp.res = View{nullptr, 0, 0, 0};
     if (a->res) fp.res = View{const_cast<float*>(a->res), cs, 0, C};
     fp.out = View{a->y, cs, 0, C};
+    fp.out_bf16 = (g_dbg_bf16_storage && !a->res) ? 1 : 0;
     const int rpb = 256 / (cs / 4);
     if (!rc) {
         if (fp.part_rows <= kBnFuseRows) {

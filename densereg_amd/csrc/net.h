@@ -22,6 +22,12 @@ struct Tensor {
     int grad_C = 0;                    // channels [0, grad_C) of the gradient have a consumer (plan_backward): the tail of a
                                        // concat buffer written by an op without a backward (the uvd planes) needs no dgrad
     std::string tag;
+    // bf16 matrix-core training: an activation whose ONLY reader is a conv (its A operand and, in the backward sweep, that conv's
+    // weight-gradient x operand) may be stored as bf16 by its BatchReNorm apply pass -- both readers round it to bf16 while staging
+    // anyway.  reader_op: that conv's index in dr_handle::ops (plan_backward), -1 = not eligible; is_bf16: what the buffer
+    // holds after the forward in progress.
+    int reader_op = -1;
+    bool is_bf16 = false;
 };
 
 struct TView {
@@ -204,6 +210,7 @@ struct dr_handle {
     int* bn_flags = nullptr;                                // [2 counters + 2 expiry flags] per conv: look-back hand-off of the BatchReNorm
                                                             // coefficients (train_kernels.h), opt-in with DR_BN_LOOKBACK=1 (measured slower)
     bool bn_lookback = false;
+    bool bf16_act = true;                                   // DR_BF16_ACT=0: single-conv-reader activations stay fp32 on the bf16 path
     bool bf16_draw = true;                                  // DR_BF16_DRAW=0: dRaw stays fp32 on the bf16 matrix-core path (train_exec.inc)
     bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold
     const float* dm_train = nullptr;                       // input of the last dr_forward_train

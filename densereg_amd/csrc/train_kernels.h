@@ -40,6 +40,8 @@ struct BnTrainParams {
     int relu;
     View res, out;
     int* flag; int flag_target;                 // look-back hand-off (bn_train_apply_kernel<2>): groups published so far / wanted
+    int out_bf16;                               // out holds bf16 elements (same element stride out.cs; whole channel groups of four,
+                                                // no residual): the activation's only readers round it to bf16 while staging
 };
 
 // Look-back hand-off of per-channel coefficients inside ONE launch instead of a separate finalize launch per layer and
@@ -273,7 +275,10 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
                     if (cg * 4 + k < p.C) v[k] += rs[k];
             }
             float* o = p.out.p + m * p.out.cs + p.out.coff + cg * 4;
-            if (vec_out) {
+            if (p.out_bf16) {                                               // pad channels of the group: zero, like every producer of bf16 storage
+                const dr_f32x4 f = {cg * 4 + 0 < p.C ? v[0] : 0.f, cg * 4 + 1 < p.C ? v[1] : 0.f, cg * 4 + 2 < p.C ? v[2] : 0.f, cg * 4 + 3 < p.C ? v[3] : 0.f};
+                *reinterpret_cast<dr_bf16x4*>(reinterpret_cast<__bf16*>(p.out.p) + m * p.out.cs + p.out.coff + cg * 4) = __builtin_convertvector(f, dr_bf16x4);
+            } else if (vec_out) {
                 *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll

@@ -110,8 +110,8 @@ def _run(be, B, H, W, Cin, Cout, k, relu=True, with_res=False, consumer=None, se
     rc = be.lib.dr_dbg_bn_layer(C.byref(a), be.stream)
     assert rc == 0, rc
     be.sync()
-    if return_raw_draw:                       # the draw buffer as the kernel left it (bf16-storage check of the training tests)
-        return be.host(o['draw']).reshape(M, cs).copy()
+    if return_raw_draw:                       # the draw / y buffers as the kernels left them (bf16-storage check of the training tests)
+        return be.host(o['draw']).reshape(M, cs).copy(), be.host(o['y']).reshape(M, cs).copy()
     ref = _reference(x, w, gamma, beta, mm, mv, r_max, d_max, relu, res, dout, gr, wr)
     got = {n: be.host(v).reshape(B, H, W, cs)[..., :Cout] for n, v in o.items()}
     gv = {n: be.host(v) for n, v in ov.items()}

@@ -287,7 +287,7 @@ def test_bf16_draw_storage_is_numerically_transparent(be):
         # ---- (3) weight gradient: g stored as bf16
         for (cin, cout, k, hw, T) in ((40, 61, 3, (6, 6), 64), (130, 70, 1, (5, 8), 128), (64, 36, 3, (4, 4), 64)):
             B = 2
-            x = rng.standard_normal((B,) + hw + (cin,)).astype(np.float32)
+            x = bf16_round(rng.standard_normal((B,) + hw + (cin,)).astype(np.float32))
             g = bf16_round(rng.standard_normal((B,) + hw + (cout,)).astype(np.float32))
             x_cs, g_cs = -(-cin // 4) * 4, -(-cout // 4) * 4
             xp = np.zeros((B,) + hw + (x_cs,), np.float32); xp[..., :cin] = x
@@ -296,7 +296,8 @@ def test_bf16_draw_storage_is_numerically_transparent(be):
             for stored in (0, 1):
                 assert lib.dr_dbg_force_bf16_storage(stored) == 0
                 gin = np.concatenate([to_bf16_bits(gp).reshape(-1), np.full(64, 0x7FC0, np.uint16)]) if stored else gp
-                d_x, d_g = be.dev(xp), be.dev(gin)
+                xin = np.concatenate([to_bf16_bits(xp).reshape(-1), np.full(64, 0x7FC0, np.uint16)]) if stored else xp
+                d_x, d_g = be.dev(xin), be.dev(gin)
                 d_w = be.dev(np.zeros((k, k, cin, cout), np.float32))
                 rc = lib.dr_dbg_wgrad(B, hw[0], hw[1], cin, cout, k, be.ptr(d_x), x_cs, be.ptr(d_g), g_cs, None, 0.0, T, 3, be.ptr(d_w), be.stream)
                 assert rc == 0, rc
@@ -307,21 +308,22 @@ def test_bf16_draw_storage_is_numerically_transparent(be):
         lib.dr_dbg_force_bf16_storage(0)
         lib.dr_dbg_force_bf16(0)
         lib.dr_dbg_force_tile(-1)
-    # ---- (1) BatchReNorm backward apply: bf16 draw == RNE(fp32 draw)
+    # ---- (1) BatchReNorm apply passes: bf16 draw == RNE(fp32 draw), bf16 activation == RNE(fp32 activation), pads zero
     for case in ((2, 4, 4, 19, 65, 1), (8, 32, 32, 8, 78, 1)):
-        draws = []
+        bufs = []
         for stored in (0, 1):
             lib.dr_dbg_force_bf16_storage(stored)
             try:
-                d = bn_run(be, *case, relu=True, with_res=True, seed=9, return_raw_draw=True)
+                bufs.append(bn_run(be, *case, relu=True, with_res=False, seed=9, return_raw_draw=True))
             finally:
                 lib.dr_dbg_force_bf16_storage(0)
-            draws.append(d)
-        M, cs, Cout = draws[0].shape[0], draws[0].shape[1], case[4]
-        want = bf16_round(draws[0][:, :Cout])
-        bits = np.ascontiguousarray(draws[1]).view(np.uint16).reshape(-1)[:M * cs].reshape(M, cs)[:, :Cout]
-        got = (bits.astype(np.uint32) << 16).view(np.float32)
-        np.testing.assert_array_equal(got, want)
+        for which in (0, 1):                                # 0 = draw (backward apply), 1 = y (forward apply)
+            f32, b16 = bufs[0][which], bufs[1][which]
+            M, cs, Cout = f32.shape[0], f32.shape[1], case[4]
+            bits = np.ascontiguousarray(b16).view(np.uint16).reshape(-1)[:M * cs].reshape(M, cs)
+            got = (bits.astype(np.uint32) << 16).view(np.float32)
+            np.testing.assert_array_equal(got[:, :Cout], bf16_round(f32[:, :Cout]))
+            assert (got[:, Cout:] == 0).all()              # a reader's 16-byte slot may cover them
 
 
 @pytest.mark.gpu

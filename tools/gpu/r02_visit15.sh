@@ -1,16 +1,16 @@
 #!/usr/bin/env bash
-# round 2, visit 15: bf16 weight gradient with LDS transpose reads (conv_wgrad_tr.h)
+# round 2, visit 15: bf16 path A/B (last use: bf16 storage of single-conv-reader activations, DR_BF16_ACT)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 timeout 300 python -m pytest tests/test_train_parity.py tests/test_gpu_configs.py -m gpu -q --tb=short -p no:cacheprovider -k "bf16 or config5" > gpurun_out/r02_pytest_gpu15.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r02_pytest_gpu15.log
 B="timeout 200 python bench.py --no-cpu-baseline --no-forward-vote --precision bf16"
-DR_WGRAD_TR=0 $B --steps 60 --warmup 10 > gpurun_out/ab_t0.json 2> gpurun_out/ab_t0.err
-DR_WGRAD_TR=1 $B --steps 60 --warmup 10 > gpurun_out/ab_t1.json 2> gpurun_out/ab_t1.err
+DR_BF16_ACT=0 $B --steps 60 --warmup 10 > gpurun_out/ab_t0.json 2> gpurun_out/ab_t0.err
+DR_BF16_ACT=1 $B --steps 60 --warmup 10 > gpurun_out/ab_t1.json 2> gpurun_out/ab_t1.err
 C5="--num_stack 4 --num_fea 256 --in_hw 256 --dataset nyu --steps 20 --warmup 5"
-DR_WGRAD_TR=0 $B $C5 > gpurun_out/ab_c5t0.json 2> gpurun_out/ab_c5t0.err
-DR_WGRAD_TR=1 $B $C5 > gpurun_out/ab_c5t1.json 2> gpurun_out/ab_c5t1.err
+DR_BF16_ACT=0 $B $C5 > gpurun_out/ab_c5t0.json 2> gpurun_out/ab_c5t0.err
+DR_BF16_ACT=1 $B $C5 > gpurun_out/ab_c5t1.json 2> gpurun_out/ab_c5t1.err
 tail -4 gpurun_out/r02_pytest_gpu15.log
 for m in t0 t1 c5t0 c5t1; do python - <<PY
 import json

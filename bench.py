@@ -268,6 +268,11 @@ def main():
                     'launches_per_step': dom['launches'] / nprof, 'avg_launch_us': dom['total_ms'] * 1e3 / dom['launches'],
                     'algorithmic_gflop_per_launch': dom['flops'] / dom['launches'] / 1e9,
                     'share_of_step_time': dom['total_ms'] / max(sum(s['total_ms'] for s in stats), 1e-9),
+                    # the runner-up family, same accounting (training: the forward/dgrad tile and the weight gradients trade places)
+                    'runner_up': (lambda r: {'kernel': r['name'], 'achieved': r['flops'] / (r['total_ms'] * 1e-3) / 1e12,
+                                             'frac': r['flops'] / (r['total_ms'] * 1e-3) / 1e12 / peak, 'launches_per_step': r['launches'] / nprof,
+                                             'avg_launch_us': r['total_ms'] * 1e3 / r['launches']})(
+                        sorted(convs, key=lambda s: -s['total_ms'])[1]) if len(convs) > 1 else None,
                     'all_kernels': {s['name']: {'ms_per_step': s['total_ms'] / nprof, 'launches': s['launches'] // nprof,
                                                 'tflops': (s['flops'] / (s['total_ms'] * 1e-3) / 1e12) if s['flops'] else None,
                                                 'gbs': (s['bytes'] / (s['total_ms'] * 1e-3) / 1e9) if s['bytes'] else None}

@@ -1387,13 +1387,13 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     const int rpb = 256 / (cs / 4);
     if (!rc) {
         if (fp.part_rows <= kBnFuseRows) {
-            DR_LAUNCH(bn_train_apply_kernel<1>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, fp);
+            DR_LAUNCH(bn_train_apply_kernel<1>, dim3(grid_for(M, rpb, bn_grid_cap())), dim3(256), 0, s, fp);
         } else if (lookback) {
             fp.flag = flags; fp.flag_target = dr_ceil_div(C, 4);
-            DR_LAUNCH(bn_train_apply_kernel<2>, dim3(grid_for(M, rpb, 2048) + dr_ceil_div(C, 4)), dim3(256), 0, s, fp);
+            DR_LAUNCH(bn_train_apply_kernel<2>, dim3(grid_for(M, rpb, bn_grid_cap()) + dr_ceil_div(C, 4)), dim3(256), 0, s, fp);
         } else {
             DR_LAUNCH(bn_fwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, s, fp);
-            DR_LAUNCH(bn_train_apply_kernel<0>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, fp);
+            DR_LAUNCH(bn_train_apply_kernel<0>, dim3(grid_for(M, rpb, bn_grid_cap())), dim3(256), 0, s, fp);
         }
     }
     // ---- backward: backward_conv (BatchReNorm part) ------------------------------------------------
@@ -1427,13 +1427,13 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     a->bwd_rows = bp.part_rows;
     if (!rc) {
         if (bp.part_rows <= kBnFuseRows) {
-            DR_LAUNCH(bn_bwd_apply_kernel<1>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, bp);
+            DR_LAUNCH(bn_bwd_apply_kernel<1>, dim3(grid_for(M, rpb, bn_grid_cap())), dim3(256), 0, s, bp);
         } else if (lookback) {
             bp.flag = flags + 2; bp.flag_target = dr_ceil_div(C, 4);
-            DR_LAUNCH(bn_bwd_apply_kernel<2>, dim3(grid_for(M, rpb, 2048) + dr_ceil_div(C, 4)), dim3(256), 0, s, bp);
+            DR_LAUNCH(bn_bwd_apply_kernel<2>, dim3(grid_for(M, rpb, bn_grid_cap()) + dr_ceil_div(C, 4)), dim3(256), 0, s, bp);
         } else {
             DR_LAUNCH(bn_bwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, s, bp);
-            DR_LAUNCH(bn_bwd_apply_kernel<0>, dim3(grid_for(M, rpb, 2048)), dim3(256), 0, s, bp);
+            DR_LAUNCH(bn_bwd_apply_kernel<0>, dim3(grid_for(M, rpb, bn_grid_cap())), dim3(256), 0, s, bp);
         }
     }
     rt::sync_stream(s);
@@ -1569,7 +1569,7 @@ extern "C" int dr_dbg_bn_bench(long M, int C, int reduce_blocks, int iters, floa
     bp.scale = small + 6144; bp.shift = small + 7168; bp.bnc = small + 8192; bp.gamma = small + 1024;
     bp.dbeta = small + 12288; bp.dgamma = small + 13312; bp.draw = draw; bp.coef = small + 9216;
     const int rpb = 256 / (cs / 4);
-    const int g_apply = grid_for(M, rpb, 2048);
+    const int g_apply = grid_for(M, rpb, bn_grid_cap());
     const int g_reduce = reduce_blocks > 0 ? reduce_blocks : grid_for(M, rpb * 8, 256);
     bp.part = bpart; bp.part_rows = g_reduce;
     auto time_it = [&](int which) {

@@ -39,7 +39,9 @@ static std::string g_create_err;
 // (PyTorch) may have moved it
 #define DR_ENTER(h) (void)rt::set_device((h)->cfg.device)
 
-static inline int grid_for(long total, int block = 256, int cap = 256 * 8) {
+static inline int grid_for(long total, int block = 256, int cap = 0) {
+    static const int dflt = [] { const char* e = getenv("DR_ELT_GRID"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 256 * 8; }();
+    if (cap <= 0) cap = dflt;                                  // grid-stride elementwise kernels (experiment switch DR_ELT_GRID)
     long g = (total + block - 1) / block;
     return (int)std::max<long>(1, std::min<long>(g, cap));
 }

@@ -679,7 +679,10 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams p) {
         X = (X - cx0) / 100.0f;
         Y = (Y - cy0) / 100.0f;
         const float Z = (zz - cz0) / 100.0f;
-        for (int j = 0; j < p.J; ++j) {
+        // gridDim.y = 1: this thread walks all joints; gridDim.y = J: one joint per workgroup row (14-21x the threads: the
+        // per-pixel kernel was a 150 us chain of dependent strided loads and stores on 160 workgroups)
+        const int j_lo = gridDim.y > 1 ? (int)blockIdx.y : 0, j_hi = gridDim.y > 1 ? (int)blockIdx.y + 1 : p.J;
+        for (int j = j_lo; j < j_hi; ++j) {
             const float* ps = p.pose + (long)b * 3 * p.J + 3 * j;
             // 2D cone (:225-242)
             const float u = ps[0] * fx / ps[2] + cx;
@@ -723,7 +726,8 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams p) {
     __syncthreads();
     if (threadIdx.x < 3) {
         const double s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-        p.acc[(long)threadIdx.x * gridDim.x + blockIdx.x] = s;      // [3][gridDim.x] partial rows, summed by losses_out_kernel
+        // [3][gridDim.y * gridDim.x] partial rows, summed in index order by losses_out_kernel
+        p.acc[((long)threadIdx.x * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
     }
 }
 

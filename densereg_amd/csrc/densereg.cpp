@@ -501,10 +501,10 @@ void add_param(dr_handle* h, const std::string& name, std::initializer_list<int>
 
 static void free_all(dr_handle* h) {
     for (void* p : {(void*)h->flat_param, (void*)h->flat_grad, (void*)h->adam_m, (void*)h->adam_v, (void*)h->flat_state, (void*)h->flat_state_next,
-                    (void*)h->shadow, (void*)h->wp, (void*)h->wpT, (void*)h->fold, (void*)h->stats, (void*)h->bnc,
+                    (void*)h->shadow, (void*)h->wp, (void*)h->wpT, (void*)h->fold, (void*)h->bnc,
                     (void*)h->act_arena, (void*)h->grad_arena, (void*)h->scratch, (void*)h->tiny, (void*)h->tiny_ext, (void*)h->zeros,
                     (void*)h->losses, (void*)h->reg_segs, (void*)h->loss_acc, (void*)h->bn_coef, (void*)h->wg_partial, (void*)h->fold_dev, h->pack_dev, h->zero_dev,
-                    (void*)h->g_keep_arena, (void*)h->group_dev, (void*)h->bn_flags})
+                    (void*)h->g_keep_arena, (void*)h->pool_arg_arena, (void*)h->group_dev, (void*)h->bn_flags})
         if (p) rt::dfree(p);
     for (int l = 1; l < DR_MAX_LANES; ++l) {
         if (h->scratch_l[l]) rt::dfree(h->scratch_l[l]);
@@ -558,7 +558,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
     b.detect_net();
 
     // ---- parameter registry + flat layouts (TF creation order) -------------------------------
-    size_t nt = 0, ns = 0, nsh = 0, nwp = 0, nwpT = 0, nfold = 0, nstat = 0, nbnc = 0;
+    size_t nt = 0, ns = 0, nsh = 0, nwp = 0, nwpT = 0, nfold = 0, nbnc = 0;
     for (int i = 0; i < (int)h->convs.size(); ++i) {
         ConvLayer& c = h->convs[i];
         const int taps = c.k * c.k;
@@ -575,7 +575,6 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
             add_param(h, bp + "curr_t", {1}, false, PK_CURRT, i);
             c.shadow_off = nsh; nsh += 2 * (size_t)c.cout;
             c.fold_off = nfold; nfold += 2 * (size_t)c.cout;
-            c.stat_off = nstat; nstat += 4 * (size_t)c.cout;
             c.bnc_off = nbnc; nbnc += 4 * (size_t)c.cout;
         } else {
             add_param(h, c.name + "/biases", {c.cout}, true, PK_BIAS, i); c.bias_off = nt; nt += c.cout;
@@ -588,7 +587,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         }
     }
     h->n_train = nt; h->n_state = ns; h->n_shadow = nsh; h->n_wp = nwp; h->n_wpT = nwpT; h->n_fold = nfold;
-    h->n_stats = nstat; h->n_bnc = nbnc;
+    h->n_bnc = nbnc;
 
     // ---- allocation ------------------------------------------------------------------------------
     const size_t MB = (size_t)cfg->max_batch;
@@ -666,8 +665,6 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         alloc_f(h->flat_state_next, ns);
         alloc_f(h->wpT, nwpT);
         alloc_f(h->bnc, nbnc);
-        h->stats = (double*)rt::dmalloc(std::max<size_t>(nstat, 1) * sizeof(double));
-        ok = ok && h->stats;
         h->n_gact = nact;
         alloc_f(h->grad_arena, nact);
         if (ok && alloc_training_state(h)) ok = false;
@@ -1049,7 +1046,7 @@ static int run_conv_eval(dr_handle* h, const Op& op, int B, hipStream_t s) {
     return DR_OK;
 }
 
-static int run_simple_op(dr_handle* h, const Op& op, int B, hipStream_t s) {
+static int run_simple_op(dr_handle* h, const Op& op, int B, hipStream_t s, bool train = false) {
     const int kid = op.kind == OP_POOL ? KID_POOL : op.kind == OP_UPADD ? KID_UPADD : op.kind == OP_UVD ? KID_UVD : KID_COPY;
     double bytes = 0;
     if (op.kind == OP_POOL) bytes = 4.0 * B * op.in.C * ((double)op.in.t->H * op.in.t->W + (double)op.out.t->H * op.out.t->W);
@@ -1063,7 +1060,7 @@ static int run_simple_op(dr_handle* h, const Op& op, int B, hipStream_t s) {
             const int total = std::max((to->H - 1) * 2 + k - ti->H, 0);
             DR_LAUNCH(maxpool_kernel, dim3(grid_for((long)B * to->H * to->W * (op.in.C / 4))), dim3(256), 0, s,
                       (const float*)ti->p, ti->cs, op.in.coff, B, ti->H, ti->W, op.in.C, k, total / 2, total / 2, to->p,
-                      to->cs, op.out.coff, to->H, to->W);
+                      to->cs, op.out.coff, to->H, to->W, train ? op.pool_arg : (unsigned char*)nullptr);
             break;
         }
         case OP_UPADD: {

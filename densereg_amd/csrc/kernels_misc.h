@@ -73,9 +73,11 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
 // Max pool, stride 2, TF SAME (pad only bottom/right for the sizes on this path; padding never
 // wins).  Thread = (output pixel, 4 channels).
 // ------------------------------------------------------------------------------------------
+// arg (nullable, training): [B*Ho*Wo][C] bytes, the window position ky*k+kx of the FIRST maximum in scan order -- what the
+// backward pass gathers by (no floating-point atomics, no clearing of the input gradient).
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* x, int x_cs, int x_coff, int B, int H, int W,
                                                       int C, int k, int pad_t, int pad_l, float* y, int y_cs,
-                                                      int y_coff, int Ho, int Wo) {
+                                                      int y_coff, int Ho, int Wo, unsigned char* arg) {
     const int c4n = C / 4;
     const long total = (long)B * Ho * Wo * c4n;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* x, int x_cs, 
         const int oy = int((pix / Wo) % Ho);
         const int b = int(pix / ((long)Wo * Ho));
         float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int ax = -1, ay = -1, az = -1, aw = -1;                      // first maximum per channel (strict >; the first valid tap seeds it)
         for (int ky = 0; ky < k; ++ky) {
             const int iy = oy * 2 + ky - pad_t;
             if (iy < 0 || iy >= H) continue;
@@ -92,10 +95,15 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* x, int x_cs, 
                 const int ix = ox * 2 + kx - pad_l;
                 if (ix < 0 || ix >= W) continue;
                 const float4 v = *reinterpret_cast<const float4*>(x + ((long)(b * H + iy) * W + ix) * x_cs + x_coff + c4 * 4);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                const int t = ky * k + kx;
+                if (v.x > m.x || ax < 0) { m.x = v.x; ax = t; }
+                if (v.y > m.y || ay < 0) { m.y = v.y; ay = t; }
+                if (v.z > m.z || az < 0) { m.z = v.z; az = t; }
+                if (v.w > m.w || aw < 0) { m.w = v.w; aw = t; }
             }
         }
         *reinterpret_cast<float4*>(y + pix * y_cs + y_coff + c4 * 4) = m;
+        if (arg) *reinterpret_cast<unsigned*>(arg + pix * C + c4 * 4) = (unsigned)ax | ((unsigned)ay << 8) | ((unsigned)az << 16) | ((unsigned)aw << 24);
     }
 }
 
@@ -191,9 +199,9 @@ __global__ __launch_bounds__(256) void norm_dm_kernel(const float* dm, const flo
 }
 
 // per-channel sum / sum of squares over M rows.  grid = (row chunks), block = 256.
-// thread -> channel (tid % Cg) and row phase; fp64 accumulation, one atomic per (block, channel).
-__global__ __launch_bounds__(256) void moments_kernel(const float* x, int cs, int coff, long M, int C, double* sum,
-                                                      double* sq) {
+// thread -> channel (tid % Cg) and row phase; fp64 accumulation; one partial row per workgroup, part[2][C][gridDim.x], which
+// the BatchReNorm finalize folds in a fixed order (no floating-point atomics on the training path).
+__global__ __launch_bounds__(256) void moments_kernel(const float* x, int cs, int coff, long M, int C, double* part) {
     __shared__ double s1[256];
     __shared__ double s2[256];
     const int tid = threadIdx.x;
@@ -216,8 +224,8 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, int cs, in
         if (tid < cpb && c0 + tid < C) {
             double ta = 0.0, tb = 0.0;
             for (int r = 0; r < rows_par; ++r) { ta += s1[r * cpb + tid]; tb += s2[r * cpb + tid]; }
-            atomicAdd(&sum[c0 + tid], ta);
-            atomicAdd(&sq[c0 + tid], tb);
+            part[(long)(c0 + tid) * gridDim.x + blockIdx.x] = ta;
+            part[((long)C + c0 + tid) * gridDim.x + blockIdx.x] = tb;
         }
         __syncthreads();
     }

@@ -58,7 +58,6 @@ struct ConvLayer {
     int KpT = 0, NpT = 0;              // dgrad:    [taps][KpT][NpT]  (cout -> K, cin -> N, taps flipped)
     size_t wp_off = 0, wpT_off = 0;    // offsets into the packed buffers
     size_t fold_off = 0;               // 2*cout floats: scale, shift (eval fold or train step values)
-    size_t stat_off = 0;               // 4*cout doubles: sum, sumsq (fwd) ; sum g, sum g*yhat (bwd)
     size_t bnc_off = 0;                // 4*cout floats: mean, inv_std, r, d saved by the train forward
     Tensor* raw = nullptr;             // pre-BN conv output (training)
     int bst_rows = 0;                  // backward sweep: > 0 = the consumer's dgrad already wrote this many partial rows of
@@ -84,6 +83,7 @@ struct Op {
     bool masked = false;               // depth mask on the input rows (um_v1.py:146-148)
     int dropout = -1;                  // dropout slot index (stack*2 + i) or -1
     int pool_k = 0;
+    unsigned char* pool_arg = nullptr; // training: arg-max position per pooled element, [B*Ho*Wo][C] bytes (maxpool_kernel)
     int lane = 0;                      // stream lane the op runs on (FORK/JOIN: the parent lane)
     int lane2 = 0;                     // FORK/JOIN: the child lane
     int ev = -1;                       // FORK/JOIN: index into dr_handle::lane_ev
@@ -138,7 +138,6 @@ struct dr_handle {
     float* wp = nullptr;         size_t n_wp = 0;          // packed forward weights
     float* wpT = nullptr;        size_t n_wpT = 0;         // packed dgrad weights
     float* fold = nullptr;       size_t n_fold = 0;        // per-BN-layer scale|shift
-    double* stats = nullptr;     size_t n_stats = 0;
     float* bnc = nullptr;        size_t n_bnc = 0;
     float* act_arena = nullptr;  size_t n_act = 0;
     float* grad_arena = nullptr; size_t n_gact = 0;
@@ -193,6 +192,7 @@ struct dr_handle {
     size_t n_loss_part = 0;                                // rows of the loss kernel's partial sums (loss_acc)
     void* pack_dev = nullptr; int pack_nseg = 0, pack_blocks = 0;   // segment table of the one-launch weight packing
     // grouped weight gradient of the small layers (conv_wgrad.h: conv_wgrad_group_kernel), single-stream executor
+    unsigned char* pool_arg_arena = nullptr;                // max-pool arg-max bytes (Op::pool_arg)
     float* g_keep_arena = nullptr;                          // the layers' private dRaw buffers
     std::vector<dr::WgradGroupSeg> group_host, group_uploaded;   // segments of the sweep in progress / what group_dev holds
     dr::WgradGroupSeg* group_dev = nullptr;

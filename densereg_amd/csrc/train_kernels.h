@@ -586,33 +586,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* g, int cs, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// Max-pool backward: route dOut to the first maximum of the window (scan order ky, kx; strict >),
-// the convention of torch's max_pool2d which the oracle's autograd follows.
+// Max-pool backward, as a GATHER over the recorded arg-max (maxpool_kernel): thread = (input pixel, 4 channels); each of the
+// up to 2 x 2 windows that contain the pixel hands its dOut over iff its first maximum (scan order ky, kx; strict >, the
+// convention of torch's max_pool2d which the oracle's autograd follows) sits on this pixel.  Every input element is written
+// exactly once, in a fixed order: no floating-point atomics, no clearing of dx (acc = 0: dx is overwritten).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* x, int x_cs, int x_coff, float* dx, int B, int H, int W,
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* arg, float* dx, int dx_cs, int dx_coff, int B, int H, int W,
                                                           int C, int k, int pad_t, int pad_l, const float* dy, int y_cs,
-                                                          int y_coff, int Ho, int Wo) {
-    const long total = (long)B * Ho * Wo * C;
+                                                          int y_coff, int Ho, int Wo, int acc) {
+    const int c4n = C / 4;
+    const long total = (long)B * H * W * c4n;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = int(i % C);
-        const long pix = i / C;
-        const int ox = int(pix % Wo);
-        const int oy = int((pix / Wo) % Ho);
-        const int b = int(pix / ((long)Wo * Ho));
-        float best = -INFINITY;
-        long best_off = -1;
-        for (int ky = 0; ky < k; ++ky) {
-            const int iy = oy * 2 + ky - pad_t;
-            if (iy < 0 || iy >= H) continue;
-            for (int kx = 0; kx < k; ++kx) {
-                const int ix = ox * 2 + kx - pad_l;
-                if (ix < 0 || ix >= W) continue;
-                const long off = ((long)(b * H + iy) * W + ix) * x_cs + x_coff + c;
-                const float v = x[off];
-                if (v > best || best_off < 0) { best = v; best_off = off; }
+        const int c4 = int(i % c4n);
+        const long ip = i / c4n;
+        const int ix = int(ip % W);
+        const int iy = int((ip / W) % H);
+        const int b = int(ip / ((long)W * H));
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        // windows (oy, ox) with oy*2 + ky - pad_t == iy for some ky in [0, k)
+        const int oy_hi = (iy + pad_t) >> 1, ox_hi = (ix + pad_l) >> 1;
+        for (int oy = oy_hi; oy >= 0 && oy * 2 + k - 1 - pad_t >= iy; --oy) {
+            if (oy >= Ho) continue;
+            const int ky = iy + pad_t - oy * 2;
+            for (int ox = ox_hi; ox >= 0 && ox * 2 + k - 1 - pad_l >= ix; --ox) {
+                if (ox >= Wo) continue;
+                const int kx = ix + pad_l - ox * 2;
+                const long op = ((long)b * Ho + oy) * Wo + ox;
+                const unsigned a4 = *reinterpret_cast<const unsigned*>(arg + op * C + c4 * 4);
+                const float4 d = *reinterpret_cast<const float4*>(dy + op * y_cs + y_coff + c4 * 4);
+                const unsigned t = (unsigned)(ky * k + kx);
+                if ((a4 & 0xFFu) == t) g.x += d.x;
+                if (((a4 >> 8) & 0xFFu) == t) g.y += d.y;
+                if (((a4 >> 16) & 0xFFu) == t) g.z += d.z;
+                if ((a4 >> 24) == t) g.w += d.w;
             }
         }
-        if (best_off >= 0) atomicAdd(&dx[best_off], dy[pix * y_cs + y_coff + c]);
+        float4* q = reinterpret_cast<float4*>(dx + ip * dx_cs + dx_coff + c4 * 4);
+        if (acc) { const float4 o = *q; g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
+        *q = g;
     }
 }
 

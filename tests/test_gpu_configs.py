@@ -120,11 +120,12 @@ def test_config3_nyu_train_full_batch_b40(gpu):
         hh.close()
     (lo_a, g_a), (lo_b, g_b) = runs
     assert np.isfinite(lo_a).all() and (lo_a[:3] > 0).all()
-    # reproducible up to the three fp atomics left on the path (max-pool backward scatter, stem moments): 1e-5 of each tensor
-    np.testing.assert_allclose(lo_a, lo_b, rtol=1e-6)
+    # no floating-point atomics anywhere on the path (partial rows folded in a fixed order, max-pool backward as a gather over
+    # the recorded arg-max): two fresh handles give the same bits, side stream and grouped launches included
+    np.testing.assert_array_equal(lo_a, lo_b)
     for n in g_a:
-        sc = np.abs(g_a[n]).max() + 1e-12
-        assert np.isfinite(g_a[n]).all() and np.abs(g_a[n] - g_b[n]).max() / sc < 1e-5, n
+        assert np.isfinite(g_a[n]).all(), n
+        np.testing.assert_array_equal(g_a[n], g_b[n], err_msg=n)
 
 
 # ---- config 5: S=4 F=256 on 256x256 crops ------------------------------------------------------------------------------

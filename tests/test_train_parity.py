@@ -340,8 +340,9 @@ def test_train_step_config3_nyu_two_stacks_dropout_mask(gpu):
 def test_lanes_match_single_stream(gpu, monkeypatch):
     """The executor runs the two branches of every hourglass level on separate HIP streams (net.h: lanes).
     Five training micro-steps + an eval forward with lanes on (DR_MULTI_STREAM=1) must reproduce the default single-stream handle: maps
-    bit-exact in eval (no atomics there), gradients to fp64-atomic rounding noise.  A missing event edge shows up
-    as a gross mismatch in some repetition."""
+    bit-exact in eval, gradients to fp32 summation-order noise (lanes run the weight gradients inline with their own slab plans,
+    the default puts them on the side stream / in the grouped launch).  A missing event edge shows up as a gross mismatch in
+    some repetition."""
     cfg, params, ndm, poses, cfgs, coms = _case(2, 64, 8, 6, 'nyu')
     B = ndm.shape[0]
 
@@ -373,7 +374,34 @@ def test_lanes_match_single_stream(gpu, monkeypatch):
     for step, (ga, gb) in enumerate(zip(g_multi, g_single)):
         for name in ga:
             sc = np.abs(gb[name]).max() + 1e-12
-            assert np.abs(ga[name] - gb[name]).max() / sc < 1e-4, (step, name)
+            assert np.abs(ga[name] - gb[name]).max() / sc < 1e-5, (step, name)
+
+
+def test_micro_step_is_bit_reproducible(be):
+    """forward(train) + loss + backward twice on fresh handles: identical bits.  The path has no floating-point atomics --
+    BatchReNorm sums go through per-workgroup partial rows folded in a fixed order (the stem's moments_kernel included), the
+    max-pool backward gathers over the arg-max its forward recorded, weight-gradient slabs are folded in slab order."""
+    cfg, params, ndm, poses, cfgs, coms = _case(2, 32, 5, 1 if be.name == 'emu' else 7)
+    B = ndm.shape[0]
+
+    def run():
+        h = be.handle(cfg, B, training=True)
+        h.load_params(params)
+        h.call('dr_finalize_params', be.stream)
+        d_dm, d_pose, d_cfg, d_com, d_lo = be.dev(ndm), be.dev(poses), be.dev(cfgs), be.dev(coms), be.empty((4,))
+        h.call('dr_forward_train', B, be.ptr(d_dm), 2, None, C.c_uint64(11), be.stream)
+        h.call('dr_loss', B, be.ptr(d_dm), be.ptr(d_pose), be.ptr(d_cfg), be.ptr(d_com), be.ptr(d_lo), be.stream)
+        h.call('dr_zero_grad', be.stream)
+        h.call('dr_backward', B, be.stream)
+        be.sync()
+        out = be.host(d_lo).copy(), flat_grads_by_name(be, h, cfg)
+        h.close()
+        return out
+
+    (lo_a, g_a), (lo_b, g_b) = run(), run()
+    np.testing.assert_array_equal(lo_a, lo_b)
+    for name in g_a:
+        np.testing.assert_array_equal(g_a[name], g_b[name], err_msg=name)
 
 
 def test_bn_backward_sums_fused_into_dgrad(be, monkeypatch):

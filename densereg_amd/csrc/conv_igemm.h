@@ -62,6 +62,7 @@ struct ConvParams {
     int Ng;                                // > 0: compute only the first Ng (multiple of 32, <= Np) output columns -- Np
                                            // stays the row stride of the packed weights (input gradients of a concat
                                            // buffer whose last channels have no consumer)
+    int nfast;                             // workgroup -> tile mapping: the N blocks of a row block are consecutive in dispatch order
     int bf16;                              // w holds bf16 [Kp/32][tap][Np][32] (Kp % 32 == 0): launch the BF kernels
     int x_bf16;                            // BF kernels only: x holds bf16 elements (x_cs / x_coff in elements, channel groups of 4
                                            // zero-padded): a 16-byte slot is loaded as it is, no conversion while staging
@@ -163,10 +164,19 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
     // 4 MB L2.  A 3x3 tap reads the image rows above and below a row block, i.e. its neighbours' pixels: with the
     // identity mapping neighbours sit on different XCDs and every L2 fetches every halo from HBM.  Remapped, XCD x
     // owns the contiguous range [x*nx/8, (x+1)*nx/8) of row blocks (and all their N blocks: gridDim.x % 8 == 0).
-    int mblk = blockIdx.x;
-    if ((gridDim.x & 7) == 0) mblk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // N blocks of one row block are dealt out back to back (p.nfast): they run at the same time on the same XCD, so the row
+    // block's input pixels are fetched from HBM once and re-read from L2 by the other N blocks.  With the dispatch order of a
+    // 2-D grid (x fastest) the N blocks of a row block start gridDim.x workgroups apart and each of them reads the rows from HBM.
+    int mblk = blockIdx.x, nblk = blockIdx.y;
+    if (p.nfast && gridDim.y > 1) {
+        const int L = blockIdx.y * gridDim.x + blockIdx.x, nN = gridDim.y;
+        if ((gridDim.x & 7) == 0) { const int s = L >> 3; mblk = (L & 7) * (gridDim.x >> 3) + s / nN; nblk = s % nN; }
+        else { mblk = L / nN; nblk = L % nN; }
+    } else if ((gridDim.x & 7) == 0) {
+        mblk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    }
     const int m0 = mblk * BM;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = nblk * BN;
     const int taps = p.ksize * p.ksize;
     const int KT = (p.Kp + CK - 1) / CK;
     const int T_total = taps * KT;
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
             double t = 0.0;
 #pragma unroll
             for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + col];
-            if (n < p.Cout) p.stat_part[((long)which * p.Cout + n) * gridDim.x + blockIdx.x] = t;
+            if (n < p.Cout) p.stat_part[((long)which * p.Cout + n) * gridDim.x + mblk] = t;
         }
     }
 }

@@ -52,7 +52,11 @@ static inline int grid_for(long total, int block = 256, int cap = 0) {
 namespace dr {
 
 template <int BM, int BN, int WM, int WN, int BK = 16, int GL = 0, int BF = 0, int WK = 1>
-static void launch_cfg(const ConvParams& p, hipStream_t s) {
+static void launch_cfg(const ConvParams& p_in, hipStream_t s) {
+    // N blocks of a row block back to back in dispatch order (conv_igemm.h nfast); DR_CONV_NFAST=0: plain 2-D grid order
+    static const int nfast = [] { const char* e = getenv("DR_CONV_NFAST"); return (e && e[0] == '0') ? 0 : 1; }();
+    ConvParams p = p_in;
+    p.nfast = nfast;
     const int M = p.B * p.H * p.W;
     dim3 grid(dr_ceil_div(M, BM), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, BN));
     if constexpr (BF == 1) {

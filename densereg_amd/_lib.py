@@ -92,6 +92,7 @@ SIGNATURES = {
     'dr_dbg_mfma_peak': (_i, [_i, _i, _i, C.POINTER(C.c_float)]),
     'dr_dbg_bn_layer': (_i, [C.POINTER(DbgBnArgs), _vp]),
     'dr_dbg_lookback_expired': (_i, [_vp]),
+    'dr_dbg_maxpool': (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     'dr_dbg_act_dgrad': (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, C.c_float, _vp, _vp, _vp]),
     'dr_profile_enable': (_i, [_vp, _i]),
     'dr_profile_read': (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),

@@ -1486,6 +1486,26 @@ extern "C" int dr_dbg_act_dgrad(int B, int H, int W, int C, int Cr, int kr, cons
     return (rc || rt::last_error(&m)) ? DR_E_DEVICE : DR_OK;
 }
 
+// Max-pool k x k / stride 2 (TF 'SAME') forward with the recorded arg-max and its gather backward on dense [B][H][W][C]
+// device buffers (C % 4 == 0): y, then dx = (acc ? dx : 0) + the gradient dy routed to the first maximum of every window.
+extern "C" int dr_dbg_maxpool(int B, int H, int W, int C, int k, const float* x, float* y, const float* dy, float* dx, int acc,
+                              dr_stream stream) {
+    if (!x || !y || !dy || !dx || (k != 2 && k != 3) || C < 4 || C % 4 || B < 1 || H < 1 || W < 1) return DR_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int total = std::max((Ho - 1) * 2 + k - H, 0);
+    unsigned char* arg = (unsigned char*)rt::dmalloc((size_t)B * Ho * Wo * C);
+    if (!arg) return DR_E_NOMEM;
+    DR_LAUNCH(maxpool_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(256), 0, s, x, C, 0, B, H, W, C, k, total / 2, total / 2, y, C, 0,
+              Ho, Wo, arg);
+    DR_LAUNCH(maxpool_bwd_kernel, dim3(grid_for((long)B * H * W * (C / 4))), dim3(256), 0, s, (const unsigned char*)arg, dx, C, 0, B, H, W, C, k,
+              total / 2, total / 2, dy, C, 0, Ho, Wo, acc ? 1 : 0);
+    rt::sync_stream(s);
+    rt::dfree(arg);
+    std::string m;
+    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
+}
+
 // Micro-benchmark of the weight-gradient kernel + slab fold on self-allocated buffers: microseconds per call for a
 // given channel tile T and slab count nsplit (0 = the executor's planner).
 extern "C" int dr_dbg_wgrad_bench(int B, int H, int W, int Cin, int Cout, int k, int T, int nsplit, int iters, float* us_out,

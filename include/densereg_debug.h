@@ -66,6 +66,12 @@ int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream);
 int dr_dbg_act_dgrad(int B, int H, int W, int C, int Cr, int kr, const float* out, const float* gr, int gr_cs, const float* wr,
                      float factor, float* g, float* dbias, dr_stream stream);
 
+/* Max-pool k x k / stride 2, TF 'SAME' (ops.max_pool, network/slim/ops.py:640-669) on dense [B][H][W][C] device buffers,
+ * C % 4 == 0: y [B][ceil(H/2)][ceil(W/2)][C] and, from the arg-max the forward records, dx = (acc ? dx : 0) + dy routed to
+ * the FIRST maximum of every window in scan order (the convention of the oracle's autograd). */
+int dr_dbg_maxpool(int B, int H, int W, int C, int k, const float* x, float* y, const float* dy, float* dx, int acc,
+                   dr_stream stream);
+
 /* Training handles: how many look-back waits of the BatchReNorm apply kernels expired so far (train_kernels.h: the wait is
  * bounded so that a scheduling surprise can never hang the device; it must stay 0).  Synchronises the device. */
 int dr_dbg_lookback_expired(dr_handle* h);

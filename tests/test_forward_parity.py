@@ -133,6 +133,26 @@ def test_conv_every_tile_shape(be, tile):
         assert _rel(y1, ref_conv2d(x1, w1)[0]) < 2e-5
 
 
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
+def test_conv_workgroup_order_with_several_column_blocks(be, tile):
+    """The workgroup -> tile mapping deals the N blocks of a row block out back to back (conv_igemm.h, nfast), per XCD when
+    the number of row blocks is a multiple of 8 and linearly otherwise: every (row block, column block) pair must be computed
+    exactly once -- three column blocks, with 16 / 8 row blocks (XCD form) and with 3 / 2 (linear form)."""
+    rng = np.random.default_rng(40 + tile)
+    bn = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32}[tile]
+    Cout, Cin = 3 * bn - 5, 24
+    for shape in ((4, 16, 16), (1, 9, 15)):                              # 1024 rows / 135 rows
+        x = rng.standard_normal(shape + (Cin,)).astype(np.float32)
+        w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+        shift = rng.standard_normal(Cout).astype(np.float32)
+        try:
+            assert be.lib.dr_dbg_force_tile(tile) == 0
+            y = be.conv2d(x, w, None, shift, True)
+        finally:
+            be.lib.dr_dbg_force_tile(-1)
+        assert _rel(y, ref_conv2d(x, w, None, shift, True)[0]) < 2e-5
+
+
 def test_conv_lds_dma_refill_variant(be, monkeypatch):
     """Shapes the LDS-DMA refill (DR_CONV_GLDS=1: global_load_lds, swizzle on the source side, zero page for masked
     chunks) is eligible for -- whole 16-byte channel chunks, incl. a short last chunk group (Cin = 20) -- against the

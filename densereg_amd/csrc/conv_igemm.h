@@ -392,13 +392,14 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
     __syncthreads();
 
     float abl_sink = 0.f;              // ABL 4 only
+    const float abl_frag = (ABL == 7 || ABL == 8) ? p.mask_thresh + (float)lane * 1e-3f : 0.f;   // run-time value: nothing folds away
     const int lk = lane >> 5;          // which k of the pair this lane feeds
     const int li = lane & 31;
     // One K-tile: prefetch tile t+1 into registers, MFMA over tile t from LDS buffer `buf`, park t+1 in the other
     // buffer, barrier.  `buf` is a compile-time constant in every call (the K loop below is unrolled by two), so
     // each ds_read / ds_write address is "base + immediate" instead of a per-access VALU add.
     auto k_tile = [&](const int buf, const bool more_) __attribute__((always_inline)) {
-        const bool more = ABL != 1 && more_;
+        const bool more = ABL != 1 && ABL < 6 && more_;                   // ABL 6..8: no refills, and (6) no barrier, (7) fragments read once, (8) both
         const bool was_tail = ld_kc + CK > p.Cin;                           // of the tile being fetched now
         if (more && ABL != 5) load_tile(buf ^ 1);
         // WK = 2: this wave multiplies only the k-slot group g = wk of the tile (the other half belongs to its partner wave)
@@ -407,6 +408,13 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int kg = WK > 1 ? wk * 8 : g * 8;              // first k of the group
+            if (ABL == 7 || ABL == 8) {                           // ablation: no LDS reads in the loop (values made up from the lane id)
+#pragma unroll
+                for (int i = 0; i < T::kTM; ++i) a4[g][i] = make_float4(abl_frag, abl_frag + 1.f, abl_frag + 2.f, abl_frag + 3.f);
+#pragma unroll
+                for (int j = 0; j < T::kTN; ++j) b4[g][j] = make_float4(abl_frag, abl_frag - 1.f, abl_frag - 2.f, abl_frag - 3.f);
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < T::kTM; ++i)
                 a4[g][i] = *reinterpret_cast<const float4*>(&DR_AS(buf)[wm * T::kWTM + i * 32 + li][(kg + lk * 4) ^ T::swz(li)]);
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
         } else if (more) {
             if constexpr (!GL) store_tile(buf ^ 1, was_tail);
         }
-        __syncthreads();
+        if (ABL != 6 && ABL != 8) __syncthreads();
     };
     // Pairs of K-tiles run unconditionally (a K-tile under "if (t < T_total)" made hipcc carry the accumulators
     // in VGPRs and copy all of them to and from the AGPRs around every MFMA block); an odd last tile follows.

@@ -235,8 +235,13 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
         const int c = cg * 4 + k;
         if (FUSE) { sc[k] = s_sc[c]; sh[k] = s_sh[c]; }
         else {
-            sc[k] = c < p.C ? p.scale[c] : 0.f;                // written by bn_fwd_finalize_kernel
-            sh[k] = c < p.C ? p.shift[c] : 0.f;
+            // UNCONDITIONAL loads (index clamped; a pad channel computes garbage that no store keeps): behind "c < C ? load : 0"
+            // hipcc parks an s_waitcnt vmcnt(0) at the join, and the coefficient round trip (written by the finalize launch on
+            // other XCDs: an L2 miss) was paid before the first streaming load was even issued -- two dependent round trips in
+            // launches that last 5 us.
+            const int cc = c < p.C ? c : p.C - 1;
+            sc[k] = p.scale[cc];                                // written by bn_fwd_finalize_kernel
+            sh[k] = p.shift[cc];
         }
     }
     const bool full = cg * 4 + 4 <= p.C;
@@ -324,10 +329,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
         float sc[4], sh[4], mean[4], istd[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c = cg * 4 + k;
-            const bool ok = c < p.C;
-            sc[k] = ok ? p.scale[c] : 0.f; sh[k] = ok ? p.shift[c] : 0.f;
-            mean[k] = ok ? p.bnc[c] : 0.f; istd[k] = ok ? p.bnc[p.C + c] : 0.f;
+            const int c = cg * 4 + k, cc = c < p.C ? c : p.C - 1;          // unconditional loads, see bn_train_apply_kernel
+            sc[k] = p.scale[cc]; sh[k] = p.shift[cc];
+            mean[k] = p.bnc[cc]; istd[k] = p.bnc[p.C + cc];
         }
         const bool full = cg * 4 + 4 <= p.C;
         const bool vec_d = full && (p.dout.coff % 4 == 0) && (p.dout.cs % 4 == 0);
@@ -458,20 +462,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
     float sc[4], sh[4], mean[4], istd[4], c1[4], c2[4], c3[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int c = cg * 4 + k;
-        sc[k] = sh[k] = mean[k] = istd[k] = c1[k] = c2[k] = c3[k] = 0.f;
-        if (c < p.C) {
-            sc[k] = p.scale[c]; sh[k] = p.shift[c]; mean[k] = p.bnc[c]; istd[k] = p.bnc[p.C + c];
-            if (FUSE) { c1[k] = s_c[0][c]; c2[k] = s_c[1][c]; c3[k] = s_c[2][c]; }
-            else { c1[k] = p.coef[c]; c2[k] = p.coef[p.C + c]; c3[k] = p.coef[2 * p.C + c]; }
-        }
+        const int c = cg * 4 + k, cc = c < p.C ? c : p.C - 1;              // unconditional loads, see bn_train_apply_kernel
+        sc[k] = p.scale[cc]; sh[k] = p.shift[cc]; mean[k] = p.bnc[cc]; istd[k] = p.bnc[p.C + cc];
+        if (FUSE) { c1[k] = s_c[0][cc]; c2[k] = s_c[1][cc]; c3[k] = s_c[2][cc]; }
+        else { c1[k] = p.coef[cc]; c2[k] = p.coef[p.C + cc]; c3[k] = p.coef[2 * p.C + cc]; }
     }
     const bool full = cg * 4 + 4 <= p.C;
     const bool vec_d = full && (p.dout.coff % 4 == 0) && (p.dout.cs % 4 == 0);
     const bool vec_r = full && p.dres.p && (p.dres.coff % 4 == 0) && (p.dres.cs % 4 == 0);
     const long stride = (long)nblk * rpb;
     for (long m0 = (long)bid * rpb + rp; m0 < p.M; m0 += stride * kBnRows) {
-        float4 x4[kBnRows], d4[kBnRows];
+        float4 x4[kBnRows], d4[kBnRows], r4[kBnRows];
 #pragma unroll
         for (int u = 0; u < kBnRows; ++u) {
             const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
@@ -482,6 +483,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
             for (int u = 0; u < kBnRows; ++u) {
                 const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
                 d4[u] = *reinterpret_cast<const float4*>(p.dout.p + mc * p.dout.cs + p.dout.coff + cg * 4);
+            }
+        }
+        const bool acc_r = vec_r && p.dres_acc;                       // the residual gradient this pass adds to: same batch of loads
+        if (acc_r) {
+#pragma unroll
+            for (int u = 0; u < kBnRows; ++u) {
+                const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
+                r4[u] = *reinterpret_cast<const float4*>(p.dres.p + mc * p.dres.cs + p.dres.coff + cg * 4);
             }
         }
 #pragma unroll
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
                 float* q = p.dres.p + m * p.dres.cs + p.dres.coff + cg * 4;
                 if (vec_r) {
                     float4 v = make_float4(g[0], g[1], g[2], g[3]);
-                    if (p.dres_acc) { const float4 o4 = *reinterpret_cast<const float4*>(q); v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w; }
+                    if (acc_r) { v.x += r4[u].x; v.y += r4[u].y; v.z += r4[u].z; v.w += r4[u].w; }
                     *reinterpret_cast<float4*>(q) = v;
                 } else {
 #pragma unroll

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
     __syncthreads();
 
     float abl_sink = 0.f;              // ABL 4 only
-    const float abl_frag = (ABL == 7 || ABL == 8) ? p.mask_thresh + (float)lane * 1e-3f : 0.f;   // run-time value: nothing folds away
+    const float abl_frag = (ABL == 7 || ABL >= 8) ? p.mask_thresh + (float)lane * 1e-3f : 0.f;   // run-time value: nothing folds away
     const int lk = lane >> 5;          // which k of the pair this lane feeds
     const int li = lane & 31;
     // One K-tile: prefetch tile t+1 into registers, MFMA over tile t from LDS buffer `buf`, park t+1 in the other
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int kg = WK > 1 ? wk * 8 : g * 8;              // first k of the group
-            if (ABL == 7 || ABL == 8) {                           // ablation: no LDS reads in the loop (values made up from the lane id)
+            if (ABL == 7 || ABL >= 8) {                           // ablation: no LDS reads in the loop (values made up from the lane id)
 #pragma unroll
                 for (int i = 0; i < T::kTM; ++i) a4[g][i] = make_float4(abl_frag, abl_frag + 1.f, abl_frag + 2.f, abl_frag + 3.f);
 #pragma unroll
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
         } else if (more) {
             if constexpr (!GL) store_tile(buf ^ 1, was_tail);
         }
-        if (ABL != 6 && ABL != 8) __syncthreads();
+        if (ABL != 6 && ABL < 8) __syncthreads();                         // ABL 9 = 8 + no epilogue stores
     };
     // Pairs of K-tiles run unconditionally (a K-tile under "if (t < T_total)" made hipcc carry the accumulators
     // in VGPRs and copy all of them to and from the AGPRs around every MFMA block); an odd last tile follows.

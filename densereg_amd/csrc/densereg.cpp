@@ -1677,6 +1677,9 @@ extern "C" int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, 
         } else if (abl == 7) {                         // 64x128 tile without refills: LDS reads + MFMA + barriers only
             dim3 grid(dr_ceil_div(Mi, 64), dr_ceil_div(Np, 128));
             DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 1>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
+        } else if (abl == 13) {                        // 12 without the epilogue stores
+            dim3 grid(dr_ceil_div(Mi, 64), dr_ceil_div(Np, 128));
+            DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 9>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
         } else if (abl >= 10 && abl <= 12) {           // 64x128 tile, no refills, and: 10 no barrier / 11 no fragment reads / 12 neither
             dim3 grid(dr_ceil_div(Mi, 64), dr_ceil_div(Np, 128));
             if (abl == 10) DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 6>), grid, dim3(256), 0, (hipStream_t) nullptr, p);

@@ -31,6 +31,10 @@
 
 #include "dr_platform.h"
 
+#ifndef DR_EP_BATCH
+#define DR_EP_BATCH 8                  // conv_epilogue.inc: accumulator rows per batch of epilogue loads (8 or 16)
+#endif
+
 namespace dr {
 
 struct ConvParams {
@@ -47,7 +51,7 @@ struct ConvParams {
     const unsigned char* drop;                       // nullable: keep mask [M][Cout], kept -> x2
     int drop_rng; unsigned long long drop_seed;      // drop_rng != 0: counter-based keep bit instead of `drop`
     const float* out_rowmask; float out_mask_thresh; // nullable: rows with out_rowmask[m] < thresh are not written
-    double* stat_part;                               // nullable: [2][Cout][gridDim.x] per-workgroup sum / sum-of-squares of acc
+    double* stat_part;                               // nullable: [2][Cout][gx] per-workgroup sum / sum-of-squares of acc
     const float* zeros;                              // >= 16 B of zeros in HBM: target of predicated-off loads
     // dgrad feeding a BatchReNorm layer whose output has no other consumer (bst_raw != null; needs stat_part, no
     // residual/dropout): the values written ARE that layer's complete dOut, so its backward reduction happens here --
@@ -62,6 +66,8 @@ struct ConvParams {
     int Ng;                                // > 0: compute only the first Ng (multiple of 32, <= Np) output columns -- Np
                                            // stays the row stride of the packed weights (input gradients of a concat
                                            // buffer whose last channels have no consumer)
+    int gx, gy;                            // the launch grid (set by the launcher): read with the other arguments instead of from the
+                                           // implicit arguments, whose loads sat serialised behind branches in every workgroup's prologue
     int nfast;                             // workgroup -> tile mapping: the N blocks of a row block are consecutive in dispatch order
     int bf16;                              // w holds bf16 [Kp/32][tap][Np][32] (Kp % 32 == 0): launch the BF kernels
     int x_bf16;                            // BF kernels only: x holds bf16 elements (x_cs / x_coff in elements, channel groups of 4
@@ -152,6 +158,7 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
 #define DR_AS(stage) ((stage) ? As1 : As0)
 #define DR_BS(stage) ((stage) ? Bs1 : Bs0)
 
+    DR_PIN_ARGS(p.x, p.x_cs, p.x_coff, p.Cin, p.B, p.H, p.W, p.ksize, p.w, p.Kp, p.Np, p.rowmask, p.zeros, p.nfast, p.gx, p.gy, p.Ng);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -167,13 +174,14 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
     // N blocks of one row block are dealt out back to back (p.nfast): they run at the same time on the same XCD, so the row
     // block's input pixels are fetched from HBM once and re-read from L2 by the other N blocks.  With the dispatch order of a
     // 2-D grid (x fastest) the N blocks of a row block start gridDim.x workgroups apart and each of them reads the rows from HBM.
+    const int gx = p.gx, gy = p.gy;
     int mblk = blockIdx.x, nblk = blockIdx.y;
-    if (p.nfast && gridDim.y > 1) {
-        const int L = blockIdx.y * gridDim.x + blockIdx.x, nN = gridDim.y;
-        if ((gridDim.x & 7) == 0) { const int s = L >> 3; mblk = (L & 7) * (gridDim.x >> 3) + s / nN; nblk = s % nN; }
+    if (p.nfast && gy > 1) {
+        const int L = blockIdx.y * gx + blockIdx.x, nN = gy;
+        if ((gx & 7) == 0) { const int s = L >> 3; mblk = (L & 7) * (gx >> 3) + s / nN; nblk = s % nN; }
         else { mblk = L / nN; nblk = L % nN; }
-    } else if ((gridDim.x & 7) == 0) {
-        mblk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    } else if ((gx & 7) == 0) {
+        mblk = (blockIdx.x & 7) * (gx >> 3) + (blockIdx.x >> 3);
     }
     const int m0 = mblk * BM;
     const int n0 = nblk * BN;
@@ -524,7 +532,7 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
             double t = 0.0;
 #pragma unroll
             for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + col];
-            if (n < p.Cout) p.stat_part[((long)which * p.Cout + n) * gridDim.x + mblk] = t;
+            if (n < p.Cout) p.stat_part[((long)which * p.Cout + n) * gx + mblk] = t;
         }
     }
 }

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv_splitk_kernel(const ConvParams p)
             double tsum = 0.0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) tsum += sred[(which * 4 + w) * BN + col];
-            if (n < p.Cout) p.stat_part[((long)which * p.Cout + n) * gridDim.x + blockIdx.x] = tsum;
+            if (n < p.Cout) p.stat_part[((long)which * p.Cout + n) * p.gx + blockIdx.x] = tsum;
         }
     }
 }

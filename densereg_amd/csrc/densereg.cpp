@@ -59,6 +59,7 @@ static void launch_cfg(const ConvParams& p_in, hipStream_t s) {
     p.nfast = nfast;
     const int M = p.B * p.H * p.W;
     dim3 grid(dr_ceil_div(M, BM), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, BN));
+    p.gx = (int)grid.x; p.gy = (int)grid.y;
     if constexpr (BF == 1) {
         if (p.x_bf16) { DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK, 1>), grid, dim3(256), 0, s, p); return; }
     }
@@ -133,8 +134,10 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         if (p.bf16 && p.Kp % 32) return -1;
         if (p.x_bf16) return -1;                                          // the split-K kernel stages fp32 only
         dim3 grid(dr_ceil_div((int)M, 32), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, 32));
-        if (p.bf16) DR_LAUNCH((conv_splitk_kernel<1>), grid, dim3(256), 0, s, p);
-        else DR_LAUNCH((conv_splitk_kernel<0>), grid, dim3(256), 0, s, p);
+        ConvParams q = p;
+        q.gx = (int)grid.x; q.gy = (int)grid.y;
+        if (p.bf16) DR_LAUNCH((conv_splitk_kernel<1>), grid, dim3(256), 0, s, q);
+        else DR_LAUNCH((conv_splitk_kernel<0>), grid, dim3(256), 0, s, q);
         return 0;
     }
     if (p.bf16) {
@@ -1671,22 +1674,27 @@ extern "C" int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, 
         const int Mi = (int)M;
         if (abl > 0 && abl < 4) {
             dim3 grid(dr_ceil_div(Mi, 128), dr_ceil_div(Np, 128));
+            p.gx = (int)grid.x; p.gy = (int)grid.y;
             if (abl == 1) DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
             else if (abl == 2) DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
             else DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
         } else if (abl == 7) {                         // 64x128 tile without refills: LDS reads + MFMA + barriers only
             dim3 grid(dr_ceil_div(Mi, 64), dr_ceil_div(Np, 128));
+            p.gx = (int)grid.x; p.gy = (int)grid.y;
             DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 1>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
         } else if (abl == 13) {                        // 12 without the epilogue stores
             dim3 grid(dr_ceil_div(Mi, 64), dr_ceil_div(Np, 128));
+            p.gx = (int)grid.x; p.gy = (int)grid.y;
             DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 9>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
         } else if (abl >= 10 && abl <= 12) {           // 64x128 tile, no refills, and: 10 no barrier / 11 no fragment reads / 12 neither
             dim3 grid(dr_ceil_div(Mi, 64), dr_ceil_div(Np, 128));
+            p.gx = (int)grid.x; p.gy = (int)grid.y;
             if (abl == 10) DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 6>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
             else if (abl == 11) DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 7>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
             else DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 8>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
         } else if (abl == 8 || abl == 9) {             // 64x128 tile: refill loads without LDS writes / LDS writes without loads
             dim3 grid(dr_ceil_div(Mi, 64), dr_ceil_div(Np, 128));
+            p.gx = (int)grid.x; p.gy = (int)grid.y;
             if (abl == 8) DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 4>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
             else DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 5>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
         } else {

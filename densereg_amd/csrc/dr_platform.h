@@ -104,6 +104,39 @@ inline void graph_destroy(Graph g) { if (g.exec) (void)hipGraphExecDestroy(g.exe
 }}  // namespace dr::rt
 #endif
 
+// Pin kernel arguments into scalar registers HERE, as one batch of scalar loads behind a single wait: hipcc loads struct
+// arguments lazily, a field at a time behind the branches that first need it, and in the prologue of a short kernel every such
+// load is another serialised trip to the scalar cache (a miss goes to L2 / HBM: the argument buffer was just written by the host).
+#if defined(DR_EMU)
+#define DR_PIN_ARGS(...) ((void)0)
+#else
+#define DR_PIN1(a) asm volatile("" ::"s"(a))
+#define DR_PIN_ARGS_1(a) DR_PIN1(a)
+#define DR_PIN_ARGS_2(a, ...) DR_PIN1(a); DR_PIN_ARGS_1(__VA_ARGS__)
+#define DR_PIN_ARGS_3(a, ...) DR_PIN1(a); DR_PIN_ARGS_2(__VA_ARGS__)
+#define DR_PIN_ARGS_4(a, ...) DR_PIN1(a); DR_PIN_ARGS_3(__VA_ARGS__)
+#define DR_PIN_ARGS_5(a, ...) DR_PIN1(a); DR_PIN_ARGS_4(__VA_ARGS__)
+#define DR_PIN_ARGS_6(a, ...) DR_PIN1(a); DR_PIN_ARGS_5(__VA_ARGS__)
+#define DR_PIN_ARGS_7(a, ...) DR_PIN1(a); DR_PIN_ARGS_6(__VA_ARGS__)
+#define DR_PIN_ARGS_8(a, ...) DR_PIN1(a); DR_PIN_ARGS_7(__VA_ARGS__)
+#define DR_PIN_ARGS_9(a, ...) DR_PIN1(a); DR_PIN_ARGS_8(__VA_ARGS__)
+#define DR_PIN_ARGS_10(a, ...) DR_PIN1(a); DR_PIN_ARGS_9(__VA_ARGS__)
+#define DR_PIN_ARGS_11(a, ...) DR_PIN1(a); DR_PIN_ARGS_10(__VA_ARGS__)
+#define DR_PIN_ARGS_12(a, ...) DR_PIN1(a); DR_PIN_ARGS_11(__VA_ARGS__)
+#define DR_PIN_ARGS_13(a, ...) DR_PIN1(a); DR_PIN_ARGS_12(__VA_ARGS__)
+#define DR_PIN_ARGS_14(a, ...) DR_PIN1(a); DR_PIN_ARGS_13(__VA_ARGS__)
+#define DR_PIN_ARGS_15(a, ...) DR_PIN1(a); DR_PIN_ARGS_14(__VA_ARGS__)
+#define DR_PIN_ARGS_16(a, ...) DR_PIN1(a); DR_PIN_ARGS_15(__VA_ARGS__)
+#define DR_PIN_ARGS_17(a, ...) DR_PIN1(a); DR_PIN_ARGS_16(__VA_ARGS__)
+#define DR_PIN_ARGS_18(a, ...) DR_PIN1(a); DR_PIN_ARGS_17(__VA_ARGS__)
+#define DR_PIN_ARGS_19(a, ...) DR_PIN1(a); DR_PIN_ARGS_18(__VA_ARGS__)
+#define DR_PIN_ARGS_20(a, ...) DR_PIN1(a); DR_PIN_ARGS_19(__VA_ARGS__)
+#define DR_PIN_COUNT(_1, _2, _3, _4, _5, _6, _7, _8, _9, _10, _11, _12, _13, _14, _15, _16, _17, _18, _19, _20, N, ...) N
+#define DR_PIN_CAT(a, b) a##b
+#define DR_PIN_SEL(n) DR_PIN_CAT(DR_PIN_ARGS_, n)
+#define DR_PIN_ARGS(...) do { DR_PIN_SEL(DR_PIN_COUNT(__VA_ARGS__, 20, 19, 18, 17, 16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1))(__VA_ARGS__); } while (0)
+#endif
+
 // 16-byte asynchronous global -> LDS copy (LDS-DMA): lane l of the wave writes lds_wave_base + 16*l; `src` is per lane.
 #if defined(DR_EMU)
 static inline void dr_glds16(const float* src, float* lds_wave_base) { memcpy(lds_wave_base + (threadIdx.x & 63) * 4, src, 16); }

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# visit 30: conv epilogue coefficient vectors as one unconditional batch per tile column: parity, per shape, inference and training step
+# visit 30/31: conv prologue/epilogue round trips (coefficient batch, arguments pinned in one batch, grid from the arguments): parity, per shape, steps
 mkdir -p gpurun_out; G=gpurun_out
 timeout 500 python -m pytest tests/test_forward_parity.py tests/test_train_parity.py tests/test_bn_layer.py tests/test_gpu_fullsize.py -m gpu -q --tb=short -p no:cacheprovider > $G/v30_pytest.log 2>&1; echo "rc=$?" >> $G/v30_pytest.log
 timeout 300 python tools/conv_ab.py > $G/v30_conv_ab.md 2>&1

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void bias_grad_from_rows_kernel(const double* 
 }
 
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const BnTrainParams p) {
+    DR_PIN_ARGS(p.part, p.part_rows, p.C, p.M, p.beta, p.gamma, p.mm, p.mv, p.mm_next, p.mv_next, p.shadow_mean, p.shadow_var, p.shadow_step, p.scale, p.shift, p.bnc);
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= p.C) return;
     double sum, sq;
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const BnTrainParam
 // 2: look-back hand-off (above).
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams p) {
+    DR_PIN_ARGS(p.raw, p.raw_cs, p.M, p.C, p.scale, p.shift, p.relu, p.res.p, p.res.cs, p.res.coff, p.out.p, p.out.cs, p.out.coff, p.out_bf16, p.part, p.part_rows, (int)gridDim.x);
     constexpr bool FUSE = MODE == 1;
     __shared__ float s_sc[FUSE ? 1024 : 1], s_sh[FUSE ? 1024 : 1];
     // MODE 2: the grid is [ceil(C/4) producer workgroups | the streaming workgroups].  A producer folds its four channels,
@@ -318,6 +320,7 @@ struct BnBwdParams {
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p) {
+    DR_PIN_ARGS(p.dout.p, p.dout.cs, p.dout.coff, p.raw, p.raw_cs, p.M, p.C, p.relu, p.scale, p.shift, p.bnc, p.part, (int)gridDim.x);
     __shared__ double s1[256 * 4];
     __shared__ double s2[256 * 4];
     const int c4n = p.raw_cs / 4;
@@ -392,6 +395,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdParams p) {
+    DR_PIN_ARGS(p.part, p.part_rows, p.C, p.M, p.gamma, p.bnc, p.coef, p.dbeta, p.dgamma);
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= p.C) return;
     double sg, sgy;
@@ -409,6 +413,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdParams 
 // MODE 0: coefficients from a bn_bwd_finalize_kernel launch; 1 (FUSE): fold the few partial rows here; 2: look-back hand-off
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) {
+    DR_PIN_ARGS(p.dout.p, p.dout.cs, p.dout.coff, p.raw, p.raw_cs, p.M, p.C, p.relu, p.scale, p.shift, p.bnc, p.coef, p.draw, p.dres.p, p.dres.cs, p.dres.coff, p.dres_acc, p.draw_bf16, p.part, p.part_rows);
     constexpr bool FUSE = MODE == 1;
     __shared__ float s_c[FUSE ? 3 : 1][FUSE ? 1024 : 1];
     const int nprod = MODE == 2 ? (p.C + 3) >> 2 : 0;          // [producers | streaming workgroups], see bn_train_apply_kernel

@@ -17,6 +17,7 @@ namespace dr {
 
 template <int BF, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_splitk_kernel(const ConvParams p) {
+    DR_PIN_ARGS(p.x, p.x_cs, p.x_coff, p.Cin, p.B, p.H, p.W, p.ksize, p.w, p.Kp, p.Np, p.rowmask, p.zeros, p.gx);
     constexpr int BM = 32, BN = 32;
     constexpr int CK = BF ? 32 : 16;      // input channels per K-tile
     constexpr int CS = BF ? 8 : 4;        // input channels per 16-byte LDS slot

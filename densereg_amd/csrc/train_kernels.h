@@ -84,11 +84,18 @@ __device__ __forceinline__ void bn_handoff_wait(int* flag, int target) {
 // these passes at ~3 TB/s of the ~8 TB/s HBM.
 constexpr int kBnRows = 4;
 
-__device__ __forceinline__ void bn_channel_coeffs(const BnTrainParams& p, int c, double sum, double sq, float& sc_out, float& sh_out, bool persist) {
-    // every global read first (independent, one round trip), then the arithmetic, then the stores
-    const float mm = p.mm[c], mv = p.mv[c], g = p.gamma[c], beta = p.beta[c];
-    float sh_m = 0.f, sh_v = 0.f;
-    if (persist && p.shadow_step > 0) { sh_m = p.shadow_mean[c]; sh_v = p.shadow_var[c]; }
+// The per-channel inputs of bn_channel_coeffs, loaded BEFORE the partial rows are folded (unconditional: the shadow slots exist
+// for every BatchReNorm layer): the finalize launches are 5 us chains of dependent round trips, this one now overlaps the fold's.
+struct BnChanIn { float mm, mv, g, beta, sh_m, sh_v; };
+__device__ __forceinline__ BnChanIn bn_channel_load(const BnTrainParams& p, int c) {
+    BnChanIn in;
+    in.mm = p.mm[c]; in.mv = p.mv[c]; in.g = p.gamma[c]; in.beta = p.beta[c];
+    in.sh_m = p.shadow_mean[c]; in.sh_v = p.shadow_var[c];
+    return in;
+}
+__device__ __forceinline__ void bn_channel_coeffs(const BnTrainParams& p, int c, const BnChanIn& in, double sum, double sq, float& sc_out, float& sh_out,
+                                                  bool persist) {
+    const float mm = in.mm, mv = in.mv, g = in.g, beta = in.beta, sh_m = in.sh_m, sh_v = in.sh_v;
     const double cnt = (double)p.M;
     const double mean_d = sum / cnt;
     double var_d = sq / cnt - mean_d * mean_d;
@@ -135,15 +142,21 @@ __device__ __forceinline__ void fold_partials_wave(const double* part, int rows,
     const double* pa = part + (long)c * rows;
     const double* pb = part + ((long)C + c) * rows;
     double a = 0.0, b = 0.0;
-    int r = lane;
-    for (; r + 3 * 64 < rows; r += 4 * 64) {
-        double va[4], vb[4];
+    // eight rows per lane and operand in flight, unconditional (clamped row; the value of a row past the end is dropped): a tail
+    // loop of single loads was a round trip per 64 rows -- with the 640 rows of a 32x32 layer four trips where one does
+    for (int r0 = lane; r0 < rows; r0 += 8 * 64) {
+        double va[8], vb[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { va[u] = pa[r + u * 64]; vb[u] = pb[r + u * 64]; }
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u * 64, rc = r < rows ? r : rows - 1;
+            va[u] = pa[rc]; vb[u] = pb[rc];
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a += va[u]; b += vb[u]; }
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = r0 + u * 64 < rows;
+            a += ok ? va[u] : 0.0; b += ok ? vb[u] : 0.0;
+        }
     }
-    for (; r < rows; r += 64) { a += pa[r]; b += pb[r]; }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         a += __shfl_xor(a, o);
@@ -175,11 +188,12 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const BnTrainParam
     DR_PIN_ARGS(p.part, p.part_rows, p.C, p.M, p.beta, p.gamma, p.mm, p.mv, p.mm_next, p.mv_next, p.shadow_mean, p.shadow_var, p.shadow_step, p.scale, p.shift, p.bnc);
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= p.C) return;
+    const BnChanIn in = bn_channel_load(p, c);
     double sum, sq;
     fold_partials_wave(p.part, p.part_rows, p.C, c, sum, sq);
     if ((threadIdx.x & 63) == 0) {
         float sc, sh;
-        bn_channel_coeffs(p, c, sum, sq, sc, sh, true);
+        bn_channel_coeffs(p, c, in, sum, sq, sc, sh, true);
     }
 }
 
@@ -199,11 +213,12 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
         if ((int)blockIdx.x < nprod) {
             const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
             if (c < p.C) {
+                const BnChanIn in = bn_channel_load(p, c);
                 double sum, sq;
                 fold_partials_wave(p.part, p.part_rows, p.C, c, sum, sq);
                 if ((threadIdx.x & 63) == 0) {
                     float sc, sh;
-                    bn_channel_coeffs(p, c, sum, sq, sc, sh, true);
+                    bn_channel_coeffs(p, c, in, sum, sq, sc, sh, true);
                 }
             }
             bn_handoff_publish(p.flag, 1);
@@ -216,12 +231,13 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
         for (int c = threadIdx.x; c < p.raw_cs; c += 256) {
             float sc = 0.f, sh = 0.f;
             if (c < p.C) {
+                const BnChanIn in = bn_channel_load(p, c);
                 double sum = 0.0, sq = 0.0;
                 for (int r = 0; r < p.part_rows; ++r) {
                     sum += p.part[(long)c * p.part_rows + r];
                     sq += p.part[((long)p.C + c) * p.part_rows + r];
                 }
-                bn_channel_coeffs(p, c, sum, sq, sc, sh, bid == 0);
+                bn_channel_coeffs(p, c, in, sum, sq, sc, sh, bid == 0);
             }
             s_sc[c] = sc; s_sh[c] = sh;
         }
@@ -398,15 +414,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdParams 
     DR_PIN_ARGS(p.part, p.part_rows, p.C, p.M, p.gamma, p.bnc, p.coef, p.dbeta, p.dgamma);
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= p.C) return;
+    // everything the last lines read, before the fold (one round trip beside the fold's instead of one behind it)
+    const float r = p.bnc[2 * p.C + c], d = p.bnc[3 * p.C + c], istd = p.bnc[p.C + c], gam = p.gamma[c];
+    const float db0 = p.dbeta[c], dg0 = p.dgamma[c];
     double sg, sgy;
     fold_partials_wave(p.part, p.part_rows, p.C, c, sg, sgy);
     if ((threadIdx.x & 63) == 0) {
-        const float r = p.bnc[2 * p.C + c], d = p.bnc[3 * p.C + c], istd = p.bnc[p.C + c];
-        p.coef[0 * p.C + c] = p.gamma[c] * r * istd;
+        p.coef[0 * p.C + c] = gam * r * istd;
         p.coef[1 * p.C + c] = (float)(sg / (double)p.M);
         p.coef[2 * p.C + c] = (float)(sgy / (double)p.M);
-        p.dbeta[c] += (float)sg;
-        p.dgamma[c] += r * (float)sgy + d * (float)sg;
+        p.dbeta[c] = db0 + (float)sg;
+        p.dgamma[c] = dg0 + (r * (float)sgy + d * (float)sg);
     }
 }
 

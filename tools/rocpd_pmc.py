@@ -41,7 +41,7 @@ def short_name(n):
     m = re.search(r'conv_igemm_kernel<(\d+), (\d+)', n)
     if m:
         return 'conv_igemm_%sx%s' % (m.group(1), m.group(2))
-    if 'conv_wgrad_kernel' in n or 'conv_wgrad_bf16_kernel' in n or 'conv_wgrad_row_kernel' in n or 'conv_wgrad_group_kernel' in n:
+    if 'conv_wgrad_kernel' in n or 'conv_wgrad_bf16_kernel' in n or 'conv_wgrad_tr_kernel' in n or 'conv_wgrad_row_kernel' in n or 'conv_wgrad_group_kernel' in n:
         return 'conv_wgrad'
     return None
 

@@ -82,7 +82,10 @@ __device__ __forceinline__ void bn_handoff_wait(int* flag, int target) {
 // Streaming kernels below keep kBnRows independent 16-byte loads per thread and stream in flight: hipcc does
 // not batch the loads of a "#pragma unroll"-ed grid-stride loop by itself (it waited for each one), which held
 // these passes at ~3 TB/s of the ~8 TB/s HBM.
-constexpr int kBnRows = 4;
+#ifndef DR_BN_ROWS
+#define DR_BN_ROWS 4                     // experiment switch of the build (profiles/r02_experiments.md)
+#endif
+constexpr int kBnRows = DR_BN_ROWS;
 
 // The per-channel inputs of bn_channel_coeffs, loaded BEFORE the partial rows are folded (unconditional: the shadow slots exist
 // for every BatchReNorm layer): the finalize launches are 5 us chains of dependent round trips, this one now overlaps the fold's.

@@ -9,6 +9,7 @@ that is larger: the deep / wide configurations), (b) median <= 1e-2, and (c) not
 the same graph by more than 2x.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -217,10 +218,8 @@ def test_grouped_small_layer_wgrad_matches_per_layer_launches(be, monkeypatch):
         h.close()
         return out
     grouped, single = run(True), run(False)
-    # the look-back hand-off of the BatchReNorm coefficients vs a finalize launch per layer: the same fold code; what is
-    # left between two runs is the order of the few fp atomics on the path (stem moments, max-pool backward scatter)
     # the full-resolution layers' weight gradients on the library's low-priority side stream, released when the sweep enters
-    # an hourglass (the default; DR_WGRAD_STREAM=0 = inline): same kernels, same slab plan -> same numbers up to the fp atomics elsewhere
+    # an hourglass (the default; DR_WGRAD_STREAM=0 = inline): same kernels, same slab plan
     monkeypatch.setenv('DR_WGRAD_STREAM', '0')            # the default is on: compare with everything inline on one stream
     inline = run(True)
     monkeypatch.delenv('DR_WGRAD_STREAM')
@@ -239,7 +238,9 @@ def test_grouped_small_layer_wgrad_matches_per_layer_launches(be, monkeypatch):
             sc = np.abs(gb[n]).max() + 1e-12
             assert np.abs(ga[n] - gb[n]).max() / sc < 2e-5, n
             differs += int(np.abs(ga[n] - gb[n]).max() > 0)
-    assert differs > 0                    # other slab cuts = another summation order: the grouped path really ran
+    # other slab cuts = another summation order: the grouped path really ran (with executor lanes on, DR_MULTI_STREAM=1, the
+    # grouped launch is off by design and the two runs are bit-identical: the step has no floating-point atomics)
+    assert differs > 0 or os.environ.get('DR_MULTI_STREAM') == '1'
 
 
 def test_bf16_draw_storage_is_numerically_transparent(be):

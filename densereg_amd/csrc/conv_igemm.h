@@ -31,10 +31,6 @@
 
 #include "dr_platform.h"
 
-#ifndef DR_EP_BATCH
-#define DR_EP_BATCH 8                  // conv_epilogue.inc: accumulator rows per batch of epilogue loads (8 or 16)
-#endif
-
 namespace dr {
 
 struct ConvParams {
@@ -509,6 +505,9 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
     constexpr int EP_TM = T::kTM, EP_TN = T::kTN;
     const int ep_m0 = m0 + wm * T::kWTM, ep_n0 = n0 + wn * T::kWTN;
     const unsigned ep_rows = (WK > 1 && wk != 0) ? 0u : 0xFFFFu;       // K-split: the wk = 0 wave holds the sums
+    // one batch of 16 rows where the register budget allows it (three or two waves per SIMD), two of 8 in the five-wave kernels (16
+    // spilled there: 60-72 bytes of scratch per lane)
+    constexpr int EP_BATCH_ROWS = (BM * BN >= 128 * 128 || BK_ == 64) ? 16 : 8;
 #include "conv_epilogue.inc"
     if (p.stat_part) {
         // wave partials -> LDS (the operand tiles are dead: the K loop ended on a barrier) -> one row per workgroup

@@ -61,9 +61,14 @@ __global__ __launch_bounds__(256, 2) void conv_splitk_kernel(const ConvParams p)
     slot_setup(0, a_off0, a_taps0);
     slot_setup(1, a_off1, a_taps1);
     const bool ragged = (p.Cin & 3) != 0;
-    float4 a_reg0, a_reg1, b_reg0, b_reg1;
-    float4 a_hi0 = make_float4(0.f, 0.f, 0.f, 0.f), a_hi1 = a_hi0;         // channels 4..7 of a slot: bf16 operands only
-    int a_nv0 = CS, a_nv1 = CS;
+    // One K-tile's worth of staging registers.  THREE sets rotate, so three tiles of this wave are in flight: the chain is
+    // "load -> LDS -> MFMA" per tile with nothing else to run on the SIMD (one wave per SIMD, grids of <= 160 workgroups), and
+    // with a single set every tile paid a full memory round trip -- nine in a row for a 3x3 64->64 layer, ~10 us whatever the
+    // image size.  (Separate named structs passed by reference to always-inline lambdas: arrays of them went to scratch.)
+    struct TileRegs { float4 a0, a1, h0, h1, b0, b1; int nv0, nv1; };
+    TileRegs R0, R1, R2;
+    R0.h0 = R0.h1 = R1.h0 = R1.h1 = R2.h0 = R2.h1 = make_float4(0.f, 0.f, 0.f, 0.f);   // channels 4..7 of a slot: bf16 operands only
+    R0.nv0 = R0.nv1 = R1.nv0 = R1.nv1 = R2.nv0 = R2.nv1 = CS;
     auto load_one = [&](const int i, const int kc, const int tap, const float* ld_x, const float* ld_w, const unsigned off,
                         const unsigned tapmask, float4& areg, float4& ahi, float4& breg, int& anv) __attribute__((always_inline)) {
         const int s = lane + 64 * i;
@@ -77,15 +82,15 @@ __global__ __launch_bounds__(256, 2) void conv_splitk_kernel(const ConvParams p)
         const int brow = s >> 2;
         breg = *reinterpret_cast<const float4*>(n0 + brow < p.Np ? ld_w + (unsigned)((n0 + brow) * BKC + (s & 3) * 4) : p.zeros);
     };
-    auto load_tile = [&](const int t) __attribute__((always_inline)) {
+    auto load_tile = [&](const int t, TileRegs& R) __attribute__((always_inline)) {
         const int chunk = t / taps, tap = t - chunk * taps;
         const int kc = chunk * CK;
         const int ty = tap / p.ksize;
         const int dy = ty - pad, dx = tap - ty * p.ksize - pad;
         const float* ld_x = p.x + (long)(dy * p.W + dx) * p.x_cs + kc;
         const float* ld_w = p.w + (long)t * p.Np * BKC;                     // packed [chunk][tap][Np][16]: block t
-        load_one(0, kc, tap, ld_x, ld_w, a_off0, a_taps0, a_reg0, a_hi0, b_reg0, a_nv0);
-        load_one(1, kc, tap, ld_x, ld_w, a_off1, a_taps1, a_reg1, a_hi1, b_reg1, a_nv1);
+        load_one(0, kc, tap, ld_x, ld_w, a_off0, a_taps0, R.a0, R.h0, R.b0, R.nv0);
+        load_one(1, kc, tap, ld_x, ld_w, a_off1, a_taps1, R.a1, R.h1, R.b1, R.nv1);
     };
     auto store_one = [&](const int i, const int buf, float4 v, float4 u, const float4 breg, const int nv) __attribute__((always_inline)) {
         const int s = lane + 64 * i, r = s >> 2, k = (s & 3) * 4;
@@ -100,24 +105,16 @@ __global__ __launch_bounds__(256, 2) void conv_splitk_kernel(const ConvParams p)
         *reinterpret_cast<float4*>(&As[wave][buf][r][k ^ swz(r)]) = v;
         *reinterpret_cast<float4*>(&Bs[wave][buf][r][k ^ swz(r)]) = breg;
     };
-    auto store_tile = [&](const int buf) __attribute__((always_inline)) {
-        store_one(0, buf, a_reg0, a_hi0, b_reg0, a_nv0);
-        store_one(1, buf, a_reg1, a_hi1, b_reg1, a_nv1);
+    auto store_tile = [&](const int buf, const TileRegs& R) __attribute__((always_inline)) {
+        store_one(0, buf, R.a0, R.h0, R.b0, R.nv0);
+        store_one(1, buf, R.a1, R.h1, R.b1, R.nv1);
     };
 
     dr_f32x16 acc0, acc1;                 // two independent MFMA chains, summed at the end
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 
-    int t = wave, buf = 0;
-    if (t < T_total) {
-        load_tile(t);
-        store_tile(0);
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (; t < T_total; t += 4) {
-        const bool more = t + 4 < T_total;                                  // wave-uniform
-        if (more) load_tile(t + 4);
+    auto mfma_tile = [&](const int buf) __attribute__((always_inline)) {
         float4 a4[2], b4[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -137,9 +134,31 @@ __global__ __launch_bounds__(256, 2) void conv_splitk_kernel(const ConvParams p)
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1].z, b4[1].z, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1].w, b4[1].w, acc1, 0, 0, 0);
         }
-        if (more) store_tile(buf ^ 1);
+    };
+    // Step k of this wave (tile t = wave + 4k, LDS buffer k & 1): the register set that tile k used is free again -> tile k+3 goes
+    // into it; MFMAs over tile k; tile k+1 (loaded two steps ago) moves from its registers to the other LDS buffer.
+    auto step = [&](const int t, const int buf, TileRegs& free_set, const TileRegs& next_set) __attribute__((always_inline)) {
+        if (t + 12 < T_total) load_tile(t + 12, free_set);                 // wave-uniform
+        mfma_tile(buf);
+        if (t + 4 < T_total) store_tile(buf ^ 1, next_set);
         __builtin_amdgcn_wave_barrier();
-        buf ^= 1;
+    };
+    {
+        const int t0 = wave;
+        if (t0 < T_total) load_tile(t0, R0);
+        if (t0 + 4 < T_total) load_tile(t0 + 4, R1);
+        if (t0 + 8 < T_total) load_tile(t0 + 8, R2);
+        if (t0 < T_total) store_tile(0, R0);
+        __builtin_amdgcn_wave_barrier();
+        // six steps per round: register sets rotate with period 3, LDS buffers with period 2
+        for (int t = t0; t < T_total; t += 24) {
+            step(t, 0, R0, R1);
+            if (t + 4 < T_total) step(t + 4, 1, R1, R2);
+            if (t + 8 < T_total) step(t + 8, 0, R2, R0);
+            if (t + 12 < T_total) step(t + 12, 1, R0, R1);
+            if (t + 16 < T_total) step(t + 16, 0, R1, R2);
+            if (t + 20 < T_total) step(t + 20, 1, R2, R0);
+        }
     }
 
     // ---- sum the four K-partials: wave w keeps accumulator registers 4w .. 4w+3 (rows 8w + {0..3} + 4*lk) ------

@@ -117,7 +117,7 @@ constexpr int conv_min_waves() { return BK_ == 64 ? 2 : (BM * BN >= 128 * 128 ? 
 // while the MFMAs of the current tile run and is retired by the barrier's vmcnt(0).  The LDS image must be lane-linear,
 // so the slot swizzle moves to the SOURCE address (lane (row, s) fetches chunk s ^ f(row)); needs Cin % 4 == 0 (a
 // 16-byte chunk is copied whole or replaced by the zero page).  Measured +6..8 % on every shape in isolation (3x3 256->256:
-// 478 -> 448 us) and no difference inside the network step, so the launcher keeps it opt-in (DR_CONV_GLDS=1).
+// 478 -> 448 us); the launcher's default since round 2 (DR_CONV_GLDS=0 selects the register-staged refill).
 //
 // BF = 1: bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate) on fp32 tensors.  The LDS image keeps its
 // geometry -- 64-byte rows, four swizzled 16-byte slots -- but a slot now holds 8 bf16 channels, so a K-tile is 32

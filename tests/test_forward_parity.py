@@ -154,10 +154,10 @@ def test_conv_workgroup_order_with_several_column_blocks(be, tile):
 
 
 def test_conv_lds_dma_refill_variant(be, monkeypatch):
-    """Shapes the LDS-DMA refill (DR_CONV_GLDS=1: global_load_lds, swizzle on the source side, zero page for masked
+    """Shapes the LDS-DMA refill (the default; DR_CONV_GLDS=0 = register-staged: global_load_lds, swizzle on the source side, zero page for masked
     chunks) is eligible for -- whole 16-byte channel chunks, incl. a short last chunk group (Cin = 20) -- against the
-    reference.  The switch is read once per process: run this file with DR_CONV_GLDS=1 to exercise the variant
-    (tools/gpu/full_visit.sh does on the GPU; the default run covers the register-staged refill on the same shapes)."""
+    reference.  The switch is read once per process: run this file with DR_CONV_GLDS=0 to exercise the other variant
+    (tools/gpu/r02_switches.sh does on the GPU; the default run covers the LDS-DMA refill on the same shapes)."""
     rng = np.random.default_rng(11)
     outs = []
     for cin, cout, k, hw in ((64, 128, 3, 8), (20, 64, 1, 6), (256, 64, 3, 4)):

@@ -126,6 +126,7 @@ int conv_stat_rows(const ConvParams& p) {
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     if (p.x_cs % 4 || p.x_coff % 4 || p.Kp % 16 || p.Np % 32 || !p.zeros || p.Ng % 32 || p.Ng > p.Np) return -1;
+    if (!p.bf16 && (p.y_bf16 || p.bst_bf16 || p.x_bf16)) return -1;        // bf16-stored tensors exist for the bf16 matrix-core kernels only
     // the kernel addresses every tensor with 32-bit element offsets from its base pointer
     const long long M = (long long)p.B * p.H * p.W;
     const long long widest = std::max(std::max((long long)p.x_cs, (long long)p.y_cs), std::max((long long)p.res_cs, (long long)p.Cout));
@@ -1353,7 +1354,7 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     hipStream_t s = (hipStream_t)stream;
     const int C = a->Cout, cs = dr_round_up(C, 4), taps = a->k * a->k;
     const long M = (long)a->B * a->H * a->W;
-    const int Kp = dr_round_up(a->Cin, 16), Np = dr_round_up(C, 32);
+    const int Kp = dr_round_up(a->Cin, g_dbg_bf16 ? 32 : 16), Np = dr_round_up(C, 32);
     std::vector<void*> tmp;
     auto alloc = [&](size_t bytes) { void* q = rt::dmalloc(std::max<size_t>(bytes, 16)); tmp.push_back(q); return q; };
     float* wp = (float*)alloc((size_t)taps * Kp * Np * 4);
@@ -1383,8 +1384,10 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     rt::memset_async(a->dbeta, 0, (size_t)C * 4, s);
     float* scale = small; float* shift = small + C;
     // ---- forward: run_conv_train ---------------------------------------------------------------
-    DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, a->w, wp, taps, a->Cin, C, Kp, Np);
+    if (g_dbg_bf16) DR_LAUNCH(pack_weights_bf16_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, a->w, (__bf16*)wp, taps, a->Cin, C, Kp, Np);
+    else DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, a->w, wp, taps, a->Cin, C, Kp, Np);
     ConvParams p{};
+    p.bf16 = g_dbg_bf16;                                     // dr_dbg_force_bf16: the forward conv on the bf16 matrix cores
     p.x = a->x; p.x_cs = a->x_cs; p.Cin = a->Cin; p.B = a->B; p.H = a->H; p.W = a->W; p.ksize = a->k;
     p.w = wp; p.Kp = Kp; p.Np = Np; p.y = a->raw; p.y_cs = cs; p.Cout = C; p.stat_part = part; p.zeros = zeros;
     a->fwd_rows = conv_stat_rows(p);
@@ -1392,6 +1395,7 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     // bit 2 (value 4): the same rounded values, expanded back to fp32 and read by the fp32-storage kernels -- every result of
     // the two modes must be identical bit for bit.
     const bool raw16 = (g_dbg_bf16_storage & 2) != 0, raw_rounded = (g_dbg_bf16_storage & 4) != 0;
+    if ((raw16 || raw_rounded) && (!g_dbg_bf16 || consumer)) { cleanup(); return DR_E_UNSUPPORTED; }   // bf16 kernels only; the debug entry's consumer dgrad is fp32
     float* raw_tmp = nullptr;
     if (raw_rounded) {
         raw_tmp = (float*)rt::dmalloc((size_t)M * cs * 4);

@@ -66,9 +66,6 @@ struct ConvParams {
                                            // implicit arguments, whose loads sat serialised behind branches in every workgroup's prologue
     int nfast;                             // workgroup -> tile mapping: the N blocks of a row block are consecutive in dispatch order
     int bf16;                              // w holds bf16 [Kp/32][tap][Np][32] (Kp % 32 == 0): launch the BF kernels
-    int y_bf16;                            // BF kernels only: y holds bf16 elements (y_cs / y_coff in elements): the raw output of a BatchReNorm conv on the bf16
-                                           // path (DR_BF16_RAW); the statistics still come from the fp32 accumulators
-    int bst_bf16;                          // BF kernels only: bst_raw holds bf16 elements (row stride bst_cs elements)
     int x_bf16;                            // BF kernels only: x holds bf16 elements (x_cs / x_coff in elements, channel groups of 4
                                            // zero-padded): a 16-byte slot is loaded as it is, no conversion while staging
 };
@@ -511,7 +508,6 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
     // one batch of 16 rows where the register budget allows it (three or two waves per SIMD), two of 8 in the five-wave kernels (16
     // spilled there: 60-72 bytes of scratch per lane)
     constexpr int EP_BATCH_ROWS = (BM * BN >= 128 * 128 || BK_ == 64) ? 16 : 8;
-    constexpr bool EP_BF16_IO = BF != 0;
 #include "conv_epilogue.inc"
     if (p.stat_part) {
         // wave partials -> LDS (the operand tiles are dead: the K loop ended on a barrier) -> one row per workgroup

@@ -186,7 +186,6 @@ __global__ __launch_bounds__(256, 2) void conv_splitk_kernel(const ConvParams p)
     constexpr int EP_TM = 1, EP_TN = 1;
     const int ep_m0 = m0, ep_n0 = n0;
     const unsigned ep_rows = 0xFu << (4 * wave);
-    constexpr bool EP_BF16_IO = BF != 0;
     constexpr int EP_BATCH_ROWS = 16;     // two waves per SIMD by launch bounds: room for the whole column in one batch
 #include "conv_epilogue.inc"
 

@@ -126,7 +126,6 @@ int conv_stat_rows(const ConvParams& p) {
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     if (p.x_cs % 4 || p.x_coff % 4 || p.Kp % 16 || p.Np % 32 || !p.zeros || p.Ng % 32 || p.Ng > p.Np) return -1;
-    if (!p.bf16 && (p.y_bf16 || p.bst_bf16 || p.x_bf16)) return -1;        // bf16-stored tensors exist for the bf16 matrix-core kernels only
     // the kernel addresses every tensor with 32-bit element offsets from its base pointer
     const long long M = (long long)p.B * p.H * p.W;
     const long long widest = std::max(std::max((long long)p.x_cs, (long long)p.y_cs), std::max((long long)p.res_cs, (long long)p.Cout));
@@ -652,8 +651,6 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         }
         const char* a16 = getenv("DR_BF16_ACT");
         h->bf16_act = !(a16 && a16[0] == '0');
-        const char* r16 = getenv("DR_BF16_RAW");
-        h->bf16_raw = r16 && r16[0] == '1';
         const char* b16 = getenv("DR_BF16_DRAW");
         h->bf16_draw = !(b16 && b16[0] == '0');
         const char* lb = getenv("DR_BN_LOOKBACK");
@@ -1278,7 +1275,7 @@ extern "C" int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, cons
     else DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, w, wp, taps, Cin, Cout, Kp, Np);
     ConvParams p{};
     p.bf16 = g_dbg_bf16;
-    p.x_bf16 = (g_dbg_bf16 && (g_dbg_bf16_storage & 1)) ? 1 : 0;
+    p.x_bf16 = (g_dbg_bf16 && g_dbg_bf16_storage) ? 1 : 0;
     p.x = x; p.x_cs = x_cs; p.x_coff = 0; p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.ksize = k;
     p.w = wp; p.Kp = Kp; p.Np = Np; p.y = y; p.y_cs = y_cs; p.y_coff = 0; p.Cout = Cout;
     p.scale = scale; p.shift = shift; p.relu = relu; p.res = res; p.res_cs = res_cs; p.res_coff = 0;
@@ -1322,7 +1319,7 @@ extern "C" int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const
     p.x = x; p.x_cs = x_cs; p.Cin = Cin; p.g = g; p.g_cs = g_cs; p.Cout = Cout;
     p.B = B; p.H = H; p.W = W; p.ksize = k; p.rowmask = rowmask; p.mask_thresh = thresh;
     p.partial = partial; p.nsplit = nsplit; p.rows_per_split = rows;
-    p.g_bf16 = (g_dbg_bf16 && (g_dbg_bf16_storage & 1)) ? 1 : 0;
+    p.g_bf16 = (g_dbg_bf16 && g_dbg_bf16_storage) ? 1 : 0;
     p.x_bf16 = p.g_bf16;
     dim3 grid(dr_ceil_div(Cin, T) * dr_ceil_div(Cout, T) * taps * nsplit);
     if (g_dbg_bf16 && T == 128) launch_wgrad_bf16(p, 128, grid, s);
@@ -1338,13 +1335,6 @@ extern "C" int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const
     return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
 }
 
-// test helper of dr_dbg_bn_layer: a bf16-stored tensor expanded to fp32 (same element layout)
-namespace dr {
-__global__ __launch_bounds__(256) void bf16_expand_kernel(const __bf16* src, float* dst, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = (float)src[i];
-}
-}  // namespace dr
-
 // One conv -> BatchReNorm(train) layer, forward + backward, with the executors' launch logic (densereg_debug.h).
 extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     if (!a || !a->x || !a->w || !a->gamma || !a->beta || !a->mm || !a->mv || !a->y || !a->raw || !a->bnc || !a->mm_next ||
@@ -1354,7 +1344,7 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     hipStream_t s = (hipStream_t)stream;
     const int C = a->Cout, cs = dr_round_up(C, 4), taps = a->k * a->k;
     const long M = (long)a->B * a->H * a->W;
-    const int Kp = dr_round_up(a->Cin, g_dbg_bf16 ? 32 : 16), Np = dr_round_up(C, 32);
+    const int Kp = dr_round_up(a->Cin, 16), Np = dr_round_up(C, 32);
     std::vector<void*> tmp;
     auto alloc = [&](size_t bytes) { void* q = rt::dmalloc(std::max<size_t>(bytes, 16)); tmp.push_back(q); return q; };
     float* wp = (float*)alloc((size_t)taps * Kp * Np * 4);
@@ -1384,31 +1374,14 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     rt::memset_async(a->dbeta, 0, (size_t)C * 4, s);
     float* scale = small; float* shift = small + C;
     // ---- forward: run_conv_train ---------------------------------------------------------------
-    if (g_dbg_bf16) DR_LAUNCH(pack_weights_bf16_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, a->w, (__bf16*)wp, taps, a->Cin, C, Kp, Np);
-    else DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, a->w, wp, taps, a->Cin, C, Kp, Np);
+    DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, a->w, wp, taps, a->Cin, C, Kp, Np);
     ConvParams p{};
-    p.bf16 = g_dbg_bf16;                                     // dr_dbg_force_bf16: the forward conv on the bf16 matrix cores
     p.x = a->x; p.x_cs = a->x_cs; p.Cin = a->Cin; p.B = a->B; p.H = a->H; p.W = a->W; p.ksize = a->k;
     p.w = wp; p.Kp = Kp; p.Np = Np; p.y = a->raw; p.y_cs = cs; p.Cout = C; p.stat_part = part; p.zeros = zeros;
     a->fwd_rows = conv_stat_rows(p);
-    // dr_dbg_force_bf16_storage bit 1 (value 2): the raw output is stored as bf16 (DR_BF16_RAW) and read by the RB = 1 kernels;
-    // bit 2 (value 4): the same rounded values, expanded back to fp32 and read by the fp32-storage kernels -- every result of
-    // the two modes must be identical bit for bit.
-    const bool raw16 = (g_dbg_bf16_storage & 2) != 0, raw_rounded = (g_dbg_bf16_storage & 4) != 0;
-    if ((raw16 || raw_rounded) && (!g_dbg_bf16 || consumer)) { cleanup(); return DR_E_UNSUPPORTED; }   // bf16 kernels only; the debug entry's consumer dgrad is fp32
-    float* raw_tmp = nullptr;
-    if (raw_rounded) {
-        raw_tmp = (float*)rt::dmalloc((size_t)M * cs * 4);
-        if (!raw_tmp) { cleanup(); return DR_E_NOMEM; }
-        rt::memset_async(raw_tmp, 0, (size_t)M * cs * 4, s);
-        p.y = raw_tmp;
-    }
-    p.y_bf16 = (raw16 || raw_rounded) ? 1 : 0;
     int rc = launch_conv_igemm(p, s);
-    if (raw_rounded) DR_LAUNCH(bf16_expand_kernel, dim3(grid_for(M * cs)), dim3(256), 0, s, (const __bf16*)raw_tmp, a->raw, M * cs);
     BnTrainParams fp{};
     fp.raw = a->raw; fp.raw_cs = cs; fp.M = M; fp.C = C; fp.part = part; fp.part_rows = a->fwd_rows;
-    fp.raw_bf16 = raw16 ? 1 : 0;
     fp.beta = a->beta; fp.gamma = a->gamma; fp.mm = a->mm; fp.mv = a->mv; fp.mm_next = a->mm_next; fp.mv_next = a->mv_next;
     fp.shadow_mean = small + 2 * C; fp.shadow_var = small + 3 * C; fp.shadow_step = 1;
     fp.r_max = a->r_max; fp.d_max = a->d_max; fp.eps = 0.001f; fp.decay = 0.99f;
@@ -1416,22 +1389,17 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     fp.res = View{nullptr, 0, 0, 0};
     if (a->res) fp.res = View{const_cast<float*>(a->res), cs, 0, C};
     fp.out = View{a->y, cs, 0, C};
-    fp.out_bf16 = ((g_dbg_bf16_storage & 1) && !a->res) ? 1 : 0;
+    fp.out_bf16 = (g_dbg_bf16_storage && !a->res) ? 1 : 0;
     const int rpb = 256 / (cs / 4);
     if (!rc) {
-        const dim3 ga(grid_for(M, rpb, bn_grid_cap()));
         if (fp.part_rows <= kBnFuseRows) {
-            if (raw16) DR_LAUNCH((bn_train_apply_kernel<1, 1>), ga, dim3(256), 0, s, fp);
-            else DR_LAUNCH((bn_train_apply_kernel<1, 0>), ga, dim3(256), 0, s, fp);
+            DR_LAUNCH(bn_train_apply_kernel<1>, dim3(grid_for(M, rpb, bn_grid_cap())), dim3(256), 0, s, fp);
         } else if (lookback) {
             fp.flag = flags; fp.flag_target = dr_ceil_div(C, 4);
-            const dim3 gl(ga.x + dr_ceil_div(C, 4));
-            if (raw16) DR_LAUNCH((bn_train_apply_kernel<2, 1>), gl, dim3(256), 0, s, fp);
-            else DR_LAUNCH((bn_train_apply_kernel<2, 0>), gl, dim3(256), 0, s, fp);
+            DR_LAUNCH(bn_train_apply_kernel<2>, dim3(grid_for(M, rpb, bn_grid_cap()) + dr_ceil_div(C, 4)), dim3(256), 0, s, fp);
         } else {
             DR_LAUNCH(bn_fwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, s, fp);
-            if (raw16) DR_LAUNCH((bn_train_apply_kernel<0, 1>), ga, dim3(256), 0, s, fp);
-            else DR_LAUNCH((bn_train_apply_kernel<0, 0>), ga, dim3(256), 0, s, fp);
+            DR_LAUNCH(bn_train_apply_kernel<0>, dim3(grid_for(M, rpb, bn_grid_cap())), dim3(256), 0, s, fp);
         }
     }
     // ---- backward: backward_conv (BatchReNorm part) ------------------------------------------------
@@ -1439,15 +1407,13 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     bp.raw = a->raw; bp.raw_cs = cs; bp.M = M; bp.C = C; bp.relu = a->relu ? 1 : 0;
     bp.scale = scale; bp.shift = shift; bp.bnc = a->bnc; bp.gamma = a->gamma;
     bp.coef = small + 4 * C; bp.dbeta = a->dbeta; bp.dgamma = a->dgamma; bp.draw = a->draw;
-    bp.draw_bf16 = (g_dbg_bf16_storage & 1) ? 1 : 0;
-    bp.raw_bf16 = raw16 ? 1 : 0;
+    bp.draw_bf16 = g_dbg_bf16_storage ? 1 : 0;
     if (a->res && a->dres) { bp.dres = View{a->dres, cs, 0, C}; bp.dres_acc = 0; }
     if (!rc && !consumer) {
         rt::d2d(a->dout_used, a->dout, (size_t)M * cs * 4, s);
         bp.dout = View{a->dout_used, cs, 0, C};
         bp.part = part; bp.part_rows = grid_for(M, rpb * 8, 256);
-        if (raw16) DR_LAUNCH((bn_bwd_reduce_kernel<1>), dim3(bp.part_rows), dim3(256), 0, s, bp);
-        else DR_LAUNCH((bn_bwd_reduce_kernel<0>), dim3(bp.part_rows), dim3(256), 0, s, bp);
+        DR_LAUNCH(bn_bwd_reduce_kernel, dim3(bp.part_rows), dim3(256), 0, s, bp);
     } else if (!rc) {
         const int tr = a->kr * a->kr;
         DR_LAUNCH(pack_weights_T_kernel, dim3(grid_for((long)tr * KpT * NpT)), dim3(256), 0, s, a->wr, wpT, tr, C, a->Cr, KpT, NpT);
@@ -1458,7 +1424,7 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
             rt::d2d(a->dout_used, a->dout, (size_t)M * cs * 4, s);
             q.res = a->dout_used; q.res_cs = cs; q.res_coff = 0;
         }
-        q.stat_part = part2; q.bst_raw = a->raw; q.bst_cs = cs; q.bst_relu = a->relu ? 1 : 0; q.bst_bf16 = raw16 ? 1 : 0;
+        q.stat_part = part2; q.bst_raw = a->raw; q.bst_cs = cs; q.bst_relu = a->relu ? 1 : 0;
         q.bst_scale = scale; q.bst_shift = shift; q.bst_bnc = a->bnc;
         bp.dout = View{a->dout_used, cs, 0, C};
         bp.part = part2; bp.part_rows = conv_stat_rows(q);
@@ -1466,23 +1432,17 @@ extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
     }
     a->bwd_rows = bp.part_rows;
     if (!rc) {
-        const dim3 ga(grid_for(M, rpb, bn_grid_cap()));
         if (bp.part_rows <= kBnFuseRows) {
-            if (raw16) DR_LAUNCH((bn_bwd_apply_kernel<1, 1>), ga, dim3(256), 0, s, bp);
-            else DR_LAUNCH((bn_bwd_apply_kernel<1, 0>), ga, dim3(256), 0, s, bp);
+            DR_LAUNCH(bn_bwd_apply_kernel<1>, dim3(grid_for(M, rpb, bn_grid_cap())), dim3(256), 0, s, bp);
         } else if (lookback) {
             bp.flag = flags + 2; bp.flag_target = dr_ceil_div(C, 4);
-            const dim3 gl(ga.x + dr_ceil_div(C, 4));
-            if (raw16) DR_LAUNCH((bn_bwd_apply_kernel<2, 1>), gl, dim3(256), 0, s, bp);
-            else DR_LAUNCH((bn_bwd_apply_kernel<2, 0>), gl, dim3(256), 0, s, bp);
+            DR_LAUNCH(bn_bwd_apply_kernel<2>, dim3(grid_for(M, rpb, bn_grid_cap()) + dr_ceil_div(C, 4)), dim3(256), 0, s, bp);
         } else {
             DR_LAUNCH(bn_bwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, s, bp);
-            if (raw16) DR_LAUNCH((bn_bwd_apply_kernel<0, 1>), ga, dim3(256), 0, s, bp);
-            else DR_LAUNCH((bn_bwd_apply_kernel<0, 0>), ga, dim3(256), 0, s, bp);
+            DR_LAUNCH(bn_bwd_apply_kernel<0>, dim3(grid_for(M, rpb, bn_grid_cap())), dim3(256), 0, s, bp);
         }
     }
     rt::sync_stream(s);
-    if (raw_tmp) rt::dfree(raw_tmp);
     int hflags[4] = {0, 0, 0, 0};
     rt::d2h(hflags, flags, sizeof(hflags), s);
     rt::sync_stream(s);
@@ -1644,7 +1604,7 @@ extern "C" int dr_dbg_bn_bench(long M, int C, int reduce_blocks, int iters, floa
                 DR_LAUNCH(bn_fwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, (hipStream_t) nullptr, fp);
                 DR_LAUNCH(bn_train_apply_kernel<0>, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, fp);
             } else if (which == 1) {
-                DR_LAUNCH((bn_bwd_reduce_kernel<0>), dim3(g_reduce), dim3(256), 0, (hipStream_t) nullptr, bp);
+                DR_LAUNCH(bn_bwd_reduce_kernel, dim3(g_reduce), dim3(256), 0, (hipStream_t) nullptr, bp);
                 DR_LAUNCH(bn_bwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, (hipStream_t) nullptr, bp);
             } else {
                 DR_LAUNCH(bn_bwd_apply_kernel<0>, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, bp);
@@ -1811,7 +1771,7 @@ extern "C" int dr_dbg_force_tile(int tile) {
 
 // dr_dbg_conv2d and dr_dbg_conv_bench (abl 0) run the bf16 matrix-core kernels while on (process-global)
 extern "C" int dr_dbg_force_bf16_storage(int on) {
-    g_dbg_bf16_storage = on;
+    g_dbg_bf16_storage = on ? 1 : 0;
     return DR_OK;
 }
 

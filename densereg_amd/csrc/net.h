@@ -211,8 +211,6 @@ struct dr_handle {
                                                             // coefficients (train_kernels.h), opt-in with DR_BN_LOOKBACK=1 (measured slower)
     bool bn_lookback = false;
     bool bf16_act = true;                                   // DR_BF16_ACT=0: single-conv-reader activations stay fp32 on the bf16 path
-    bool bf16_raw = false;                                  // DR_BF16_RAW=1: raw outputs of the BatchReNorm convs stored as bf16 on the bf16 path (NOT transparent:
-                                                            // the normalisation then reads rounded values; its moments stay those of the fp32 accumulators)
     bool bf16_draw = true;                                  // DR_BF16_DRAW=0: dRaw stays fp32 on the bf16 matrix-core path (train_exec.inc)
     bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold
     const float* dm_train = nullptr;                       // input of the last dr_forward_train

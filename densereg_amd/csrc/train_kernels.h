@@ -40,7 +40,6 @@ struct BnTrainParams {
     int relu;
     View res, out;
     int* flag; int flag_target;                 // look-back hand-off (bn_train_apply_kernel<2>): groups published so far / wanted
-    int raw_bf16;                               // raw holds bf16 elements (element stride raw_cs): the RB = 1 kernel variants
     int out_bf16;                               // out holds bf16 elements (same element stride out.cs; whole channel groups of four,
                                                 // no residual): the activation's only readers round it to bf16 while staging
 };
@@ -78,19 +77,6 @@ __device__ __forceinline__ void bn_handoff_wait(int* flag, int target) {
         dr_acquire_agent();
     }
     __syncthreads();
-}
-
-// Four channels of a raw conv output row: fp32, or -- RB = 1, the bf16 matrix-core path with DR_BF16_RAW -- bf16 as the conv
-// epilogue stored it (the BatchReNorm moments come from the fp32 accumulators either way).  A compile-time variant: a run-time
-// branch around the loads keeps hipcc from issuing them as one batch.
-template <int RB>
-__device__ __forceinline__ float4 bn_load_raw4(const float* raw, long elem) {
-    if constexpr (RB) {
-        const dr_f32x4 f = __builtin_convertvector(*reinterpret_cast<const dr_bf16x4*>(reinterpret_cast<const __bf16*>(raw) + elem), dr_f32x4);
-        return make_float4(f[0], f[1], f[2], f[3]);
-    } else {
-        return *reinterpret_cast<const float4*>(raw + elem);
-    }
 }
 
 // Streaming kernels below keep kBnRows independent 16-byte loads per thread and stream in flight: hipcc does
@@ -218,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const BnTrainParam
 // folds the rows itself (serially per channel, fixed order, a few L2 hits) and workgroup 0 persists the results.
 // MODE 0: coefficients come from a bn_fwd_finalize_kernel launch; 1 (FUSE): few partial rows, every workgroup folds them;
 // 2: look-back hand-off (above).
-template <int MODE, int RB = 0>
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams p) {
     DR_PIN_ARGS(p.raw, p.raw_cs, p.M, p.C, p.scale, p.shift, p.relu, p.res.p, p.res.cs, p.res.coff, p.out.p, p.out.cs, p.out.coff, p.out_bf16, p.part, p.part_rows, (int)gridDim.x);
     constexpr bool FUSE = MODE == 1;
@@ -288,7 +274,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
 #pragma unroll
         for (int u = 0; u < kBnRows; ++u) {
             const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;     // tail rows re-read the last row
-            x[u] = bn_load_raw4<RB>(p.raw, mc * p.raw_cs + cg * 4);
+            x[u] = *reinterpret_cast<const float4*>(p.raw + mc * p.raw_cs + cg * 4);
         }
         if (vec_res) {
 #pragma unroll
@@ -347,13 +333,11 @@ struct BnBwdParams {
     float* draw;                      // out: gradient wrt the raw conv output, dense stride raw_cs
     View dres; int dres_acc;          // apply pass, nullable: residual source's gradient (+)= dOut (out = act(..) + res)
     int* flag; int flag_target;       // look-back hand-off (bn_bwd_apply_kernel<2>)
-    int raw_bf16;                     // raw holds bf16 elements (element stride raw_cs): the RB = 1 kernel variants
     int draw_bf16;                    // draw holds bf16 elements (same element stride raw_cs): both of its readers -- the layer's
                                       // dgrad and weight gradient on the bf16 matrix cores -- round it to bf16 anyway
                                       // while staging, so the numbers are the same and the tensor is half the bytes
 };
 
-template <int RB = 0>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p) {
     DR_PIN_ARGS(p.dout.p, p.dout.cs, p.dout.coff, p.raw, p.raw_cs, p.M, p.C, p.relu, p.scale, p.shift, p.bnc, p.part, (int)gridDim.x);
     __shared__ double s1[256 * 4];
@@ -379,7 +363,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
 #pragma unroll
             for (int u = 0; u < kBnRows; ++u) {
                 const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
-                x4[u] = bn_load_raw4<RB>(p.raw, mc * p.raw_cs + cg * 4);
+                x4[u] = *reinterpret_cast<const float4*>(p.raw + mc * p.raw_cs + cg * 4);
             }
             if (vec_d) {
 #pragma unroll
@@ -448,7 +432,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdParams 
 }
 
 // MODE 0: coefficients from a bn_bwd_finalize_kernel launch; 1 (FUSE): fold the few partial rows here; 2: look-back hand-off
-template <int MODE, int RB = 0>
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) {
     DR_PIN_ARGS(p.dout.p, p.dout.cs, p.dout.coff, p.raw, p.raw_cs, p.M, p.C, p.relu, p.scale, p.shift, p.bnc, p.coef, p.draw, p.dres.p, p.dres.cs, p.dres.coff, p.dres_acc, p.draw_bf16, p.part, p.part_rows);
     constexpr bool FUSE = MODE == 1;
@@ -518,7 +502,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
 #pragma unroll
         for (int u = 0; u < kBnRows; ++u) {
             const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
-            x4[u] = bn_load_raw4<RB>(p.raw, mc * p.raw_cs + cg * 4);
+            x4[u] = *reinterpret_cast<const float4*>(p.raw + mc * p.raw_cs + cg * 4);
         }
         if (vec_d) {
 #pragma unroll

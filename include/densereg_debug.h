@@ -93,10 +93,7 @@ int dr_dbg_force_bf16(int on);
 
 /* While on (process-global, with dr_dbg_force_bf16(1)): the bf16-STORAGE variants of the bf16 matrix-core kernels --
  * dr_dbg_conv2d reads x as bf16 elements (x_cs = element stride), dr_dbg_wgrad reads g as bf16 elements, dr_dbg_bn_layer
- * writes draw as bf16 elements (the executor stores a BatchReNorm layer's dRaw that way on the bf16 path).
- * `on` is a bit set: 1 = the above; 2 (with dr_dbg_force_bf16 on, layers without a consumer conv) = dr_dbg_bn_layer stores the raw conv output as bf16 and runs the kernels that read it so
- * (DR_BF16_RAW; a->raw then holds bf16 elements); 4 = the same rounded raw values expanded to fp32 and read by the fp32-storage
- * kernels (reference for 2: every output must be identical). */
+ * writes draw as bf16 elements (the executor stores a BatchReNorm layer's dRaw that way on the bf16 path). */
 int dr_dbg_force_bf16_storage(int on);
 
 /* Force the conv tile of every following launch (-1 = heuristic; ids as in dr_dbg_conv_bench).

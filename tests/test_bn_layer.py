@@ -64,7 +64,7 @@ def _reference(x, w, gamma, beta, mm, mv, r_max, d_max, relu, res, dout, gr, wr)
 
 
 def _run(be, B, H, W, Cin, Cout, k, relu=True, with_res=False, consumer=None, seed=0, r_max=3.0, d_max=5.0, both=False,
-         return_raw_draw=False, storage=None, return_all=False):
+         return_raw_draw=False):
     rng = np.random.default_rng(seed)
     cs, x_cs = -(-Cout // 4) * 4, -(-Cin // 4) * 4
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
@@ -107,21 +107,9 @@ def _run(be, B, H, W, Cin, Cout, k, relu=True, with_res=False, consumer=None, se
                        be.ptr(o['y']), be.ptr(o['raw']), be.ptr(bnc), be.ptr(ov['mm_next']), be.ptr(ov['mv_next']),
                        be.ptr(o['dout_used']), be.ptr(o['draw']), be.ptr(ov['dgamma']), be.ptr(ov['dbeta']),
                        be.ptr(o['dres']) if with_res else None, 0, 0)
-    try:
-        if storage is not None:                       # None: leave the (process-global) hook as the caller set it
-            assert be.lib.dr_dbg_force_bf16_storage(storage) == 0
-        rc = be.lib.dr_dbg_bn_layer(C.byref(a), be.stream)
-    finally:
-        if storage is not None:
-            be.lib.dr_dbg_force_bf16_storage(0)
+    rc = be.lib.dr_dbg_bn_layer(C.byref(a), be.stream)
     assert rc == 0, rc
     be.sync()
-    if return_all:                            # every buffer as the kernels left it (storage-mode comparisons)
-        out = {n: be.host(v).reshape(M, cs).copy() for n, v in o.items()}
-        out.update({n: be.host(v).copy() for n, v in ov.items()})
-        out['bnc'] = be.host(bnc).copy()
-        out['beta'], out['gamma'] = beta, gamma
-        return out
     if return_raw_draw:                       # the draw / y buffers as the kernels left them (bf16-storage check of the training tests)
         return be.host(o['draw']).reshape(M, cs).copy(), be.host(o['y']).reshape(M, cs).copy()
     ref = _reference(x, w, gamma, beta, mm, mv, r_max, d_max, relu, res, dout, gr, wr)
@@ -218,51 +206,6 @@ def test_bias_conv_backward_from_the_readers_dgrad(be):
         g = be.host(d_g).reshape(B, H, W, cs)[..., :Cc]
         assert np.abs(g - g_ref).max() / np.abs(g_ref).max() < 1e-5
         np.testing.assert_allclose(be.host(d_b) - 0.5, g_ref.sum((0, 1, 2)), rtol=1e-5, atol=1e-5 * np.abs(g_ref).sum((0, 1, 2)).max())
-
-
-def test_bn_layer_raw_output_stored_as_bf16(be):
-    """DR_BF16_RAW (bf16 matrix-core path, opt-in): the conv epilogue stores the raw output as bf16 -- exactly the nearest-even
-    bf16 of what it stores in fp32 -- while the BatchReNorm moments still come from the fp32 accumulators; the apply, backward
-    reduce and backward apply then read bf16 (the consumer's fused-sum dgrad reading it is covered by the whole-net tests under
-    DR_BF16_RAW=1).  Storage check, bit for bit: the same rounded values
-    expanded to fp32 and read by the fp32-storage kernels (debug mode 4) give identical results everywhere; and the layer output
-    is the normalisation of the ROUNDED raw values with the UNROUNDED batch statistics."""
-    from tests.common import bf16_round
-    cases = [dict(args=(2, 4, 4, 40, 78, 3), kw={}), dict(args=(1, 8, 8, 19, 65, 1), kw={}),
-             dict(args=(3, 8, 8, 16, 131, 1), kw=dict(with_res=True))]
-    if be.name == 'gpu':
-        cases += [dict(args=(4, 32, 32, 131, 65, 1), kw={}), dict(args=(40, 32, 32, 128, 256, 1), kw={}),
-                  dict(args=(40, 8, 8, 64, 64, 3), kw=dict(with_res=True))]
-    for i, cse in enumerate(cases):
-        B, H, W, Cin, Cout, k = cse['args']
-        try:                                     # the conv on the bf16 matrix cores in all three runs (the only kernels that store bf16)
-            assert be.lib.dr_dbg_force_bf16(1) == 0
-            f32 = _run(be, *cse['args'], seed=70 + i, return_all=True, storage=0, **cse['kw'])
-            b16 = _run(be, *cse['args'], seed=70 + i, return_all=True, storage=2, **cse['kw'])
-            exp = _run(be, *cse['args'], seed=70 + i, return_all=True, storage=4, **cse['kw'])
-        finally:
-            be.lib.dr_dbg_force_bf16(0)
-        M, cs = f32['raw'].shape
-        # (1) the stored bf16 raw = RNE(fp32 raw); mode 4 holds the same values as fp32
-        raw_bits = b16['raw'].reshape(-1).view(np.uint16)[:M * cs].reshape(M, cs)[:, :Cout]
-        raw_b16 = (raw_bits.astype(np.uint32) << 16).view(np.float32)
-        np.testing.assert_array_equal(raw_b16, bf16_round(f32['raw'][:, :Cout]))
-        np.testing.assert_array_equal(exp['raw'][:, :Cout], raw_b16)
-        # (2) statistics are those of the fp32 accumulators in every mode
-        for n in ('bnc', 'mm_next', 'mv_next'):
-            np.testing.assert_array_equal(b16[n], f32[n], err_msg=n)
-        # (3) bf16 storage vs the same values in fp32 storage: identical bits
-        for n in ('y', 'draw', 'dout_used', 'dres', 'dgamma', 'dbeta'):
-            a_, b_ = b16[n], exp[n]
-            if a_.ndim == 2:
-                a_, b_ = a_[:, :Cout], b_[:, :Cout]
-            np.testing.assert_array_equal(a_, b_, err_msg='%s (case %d)' % (n, i))
-        # (4) the output is the normalisation of the rounded values with the unrounded statistics
-        mean, istd, r, d = (f32['bnc'][j].astype(np.float64) for j in range(4))
-        y = ((raw_b16.astype(np.float64) - mean) * istd * r + d) * f32['gamma'] + f32['beta']
-        y = np.maximum(y, 0.0)
-        if not cse['kw'].get('with_res'):
-            assert np.abs(b16['y'][:, :Cout] - y).max() / np.abs(y).max() < 1e-5
 
 
 def test_bn_layer_lookback_handoff_opt_in(be, monkeypatch):

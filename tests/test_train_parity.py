@@ -146,11 +146,8 @@ def test_train_step_input_256(be):
     h.close()
 
 
-@pytest.mark.parametrize('raw16', [False, True])
-def test_train_step_bf16_precision(be, monkeypatch, raw16):
-    """raw16: DR_BF16_RAW=1, the raw outputs of the BatchReNorm convs stored as bf16 as well (opt-in; the normalisation then reads
-    rounded values -- more noise of the same kind, so the same criterion with the same bounds applies).
-    dr_set_precision(DR_PREC_BF16) on a training handle: forward, input-gradient and weight-gradient convolutions
+def test_train_step_bf16_precision(be):
+    """dr_set_precision(DR_PREC_BF16) on a training handle: forward, input-gradient and weight-gradient convolutions
     all round their two operands to bf16 on the way into the matrix cores (fp32 accumulation, fp32 tensors, fp32
     BatchReNorm / loss / Adam).  The oracle's statement of that arithmetic is oracle/net.py::_ConvBf16Operands.  On this
     network bf16 gradients are far noisier than fp32 ones (ReLU / max-pool switches and BatchNorm cancellation amplify
@@ -163,10 +160,6 @@ def test_train_step_bf16_precision(be, monkeypatch, raw16):
     from oracle import train
     cfg, params, ndm, poses, cfgs, coms = _case(1, 64, 4, 1 if be.name == 'emu' else 3)
     B = ndm.shape[0]
-    if raw16:
-        monkeypatch.setenv('DR_BF16_RAW', '1')
-    else:
-        monkeypatch.delenv('DR_BF16_RAW', raising=False)
     h = be.handle(cfg, B, training=True)
     h.call('dr_set_precision', 1)
     h.load_params(params)

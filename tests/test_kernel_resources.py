@@ -1,0 +1,26 @@
+"""Static guard on the product build (no GPU needed): hipcc's resource remarks for gfx950 must show NO kernel spilling registers
+to scratch, and the hot conv kernels must keep the occupancy their tile choice assumes (five waves per SIMD for the 64x128 /
+64x64 / 128x32 tiles: M = 40960 rows fall on the chip in whole rounds of five workgroups per CU, conv_igemm.h).  A change that
+adds a few live registers to a shared epilogue shows up here before it shows up as a slower step (it did: two run-time branches in
+conv_epilogue.inc once cost the bf16 kernels 20-216 bytes of scratch per lane and the fp32 step 1 %)."""
+import os
+import shutil
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+
+
+@pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs hipcc')
+def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy():
+    import kernel_resources
+    rows = kernel_resources.collect()
+    assert len(rows) > 60
+    spills = [(n, r['scratch']) for n, r in rows if r.get('scratch', 0) > 0]
+    assert not spills, spills
+    occ = {n: r['occ'] for n, r in rows}
+    for name in ('dr::conv_igemm_kernel<64, 128, 2, 2, 0, 16, 1, 0, 1, 0>', 'dr::conv_igemm_kernel<64, 64, 2, 2, 0, 16, 1, 0, 1, 0>',
+                 'dr::conv_igemm_kernel<128, 32, 4, 1, 0, 16, 0, 0, 1, 0>', 'dr::conv_igemm_kernel<64, 128, 2, 2, 0, 16, 0, 1, 1, 0>'):
+        assert occ.get(name) == 5, (name, occ.get(name))
+    assert occ['dr::conv_wgrad_kernel<128>'] >= 3 and occ['dr::bn_train_apply_kernel<0>'] >= 5

@@ -12,7 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main():
+def collect():
+    """[(demangled kernel name, {'vgpr', 'agpr', 'sgpr', 'scratch', 'lds', 'occ'})] of the product build (rebuilds the library)."""
     env = dict(os.environ, DR_HIPCC_EXTRA='-Rpass-analysis=kernel-resource-usage')
     log = subprocess.run([os.path.join(ROOT, 'build.sh')], cwd=ROOT, env=env, capture_output=True, text=True)
     text = log.stdout + log.stderr
@@ -35,17 +36,23 @@ def main():
     if not rows:
         sys.exit('no resource remarks in the build output:\n' + text[-2000:])
     names = subprocess.run(['c++filt'] + [r['name'] for r in rows], capture_output=True, text=True).stdout.strip().split('\n')
+    out, seen = [], set()
+    for r, n in sorted(zip(rows, names), key=lambda rn: rn[1]):
+        n = re.sub(r'\(.*\)$', '', n).replace('void ', '')
+        if n not in seen:
+            seen.add(n)
+            out.append((n, r))
+    return out
+
+
+def main():
+    rows = collect()
     print('# Kernel resources of libdensereg_hip.so (hipcc -Rpass-analysis=kernel-resource-usage, gfx950)\n')
     print('Static, from the compiler: registers, scratch, LDS per workgroup and the occupancy they allow. Template arguments of')
     print('`conv_igemm_kernel`: BM, BN, WM, WN, ABL (ablation, 0 = product), BK, GL (LDS-DMA refill), BF (bf16 operands).\n')
     print('| kernel | VGPRs | AGPRs | SGPRs | scratch B/lane | LDS B/workgroup | waves/SIMD |')
     print('|---|---:|---:|---:|---:|---:|---:|')
-    seen = set()
-    for r, n in sorted(zip(rows, names), key=lambda rn: rn[1]):
-        n = re.sub(r'\(.*\)$', '', n).replace('void ', '')
-        if n in seen:
-            continue
-        seen.add(n)
+    for n, r in rows:
         print('| `%s` | %s | %s | %s | %s | %s | %s |' % (n, r.get('vgpr', '-'), r.get('agpr', '-'), r.get('sgpr', '-'),
                                                       r.get('scratch', '-'), r.get('lds', '-'), r.get('occ', '-')))
 

@@ -153,6 +153,40 @@ def test_conv_workgroup_order_with_several_column_blocks(be, tile):
         assert _rel(y, ref_conv2d(x, w, None, shift, True)[0]) < 2e-5
 
 
+def test_conv_seeded_shape_sweep(be):
+    """A seeded sweep over small random problems -- batch, odd image sides, ragged channel counts, kernel size, every tile the
+    shape admits, with / without scale-shift, ReLU, residual, input row mask, statistics -- against the fp64 definition.  Index math
+    only (ragged last tiles in M, N and K, the XCD / N-fast workgroup mapping, tap masks at the image border, pad channels as
+    poison): the kernels' arithmetic is pinned by the cases above."""
+    rng = np.random.default_rng(20240927)
+    n_cases = 120 if be.name == "emu" else 96
+    for case in range(n_cases):
+        B, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(1, 12))
+        k = int(rng.choice([1, 3]))
+        Cin = int(rng.choice([1, 3, 4, 16, 19, 33, 64, 70, 131]))
+        Cout = int(rng.choice([1, 5, 14, 32, 42, 65, 78, 96, 128, 131, 160, 170]))
+        np_ = -(-Cout // 32) * 32
+        tiles = [-1, 4, 6] + ([2, 3, 5] if np_ % 64 == 0 else []) + ([0, 1] if np_ % 128 == 0 else []) + ([7] if np_ == 96 else []) + ([8] if np_ == 160 else [])
+        tile = int(rng.choice(tiles))
+        x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+        w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+        scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32) if rng.random() < 0.5 else None
+        shift = rng.standard_normal(Cout).astype(np.float32) if rng.random() < 0.5 else None
+        relu = bool(rng.random() < 0.5)
+        res = rng.standard_normal((B, H, W, Cout)).astype(np.float32) if rng.random() < 0.4 else None
+        mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if (k == 1 and rng.random() < 0.3) else None
+        try:
+            assert be.lib.dr_dbg_force_tile(tile) == 0
+            y, st = be.conv2d(x, w, scale, shift, relu, res, mask, -0.2, want_stats=True)
+        finally:
+            be.lib.dr_dbg_force_tile(-1)
+        yr, raw = ref_conv2d(x, w, scale, shift, relu, res, mask, -0.2)
+        tag = (case, B, H, W, Cin, Cout, k, tile)
+        assert _rel(y, yr) < 2e-5, tag
+        np.testing.assert_allclose(st[0], raw.sum((0, 1, 2)), rtol=1e-4, atol=1e-4, err_msg=str(tag))
+        np.testing.assert_allclose(st[1], (raw ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-4, err_msg=str(tag))
+
+
 def test_conv_lds_dma_refill_variant(be, monkeypatch):
     """Shapes the LDS-DMA refill (the default; DR_CONV_GLDS=0 = register-staged: global_load_lds, swizzle on the source side, zero page for masked
     chunks) is eligible for -- whole 16-byte channel chunks, incl. a short last chunk group (Cin = 20) -- against the

@@ -473,6 +473,36 @@ def test_wgrad_kernel_direct(be, case):
     assert np.abs(dw - ref).max() / np.abs(ref).max() < 2e-5
 
 
+def test_wgrad_seeded_shape_sweep(be):
+    """A seeded sweep over small random weight-gradient problems -- odd image sides, ragged channel counts, both channel tiles and
+    the kernel-row variant, any number of slabs, masked input rows -- against the fp64 einsum of the definition (index math: slab
+    ends inside a pixel step, ragged last channel tiles, tap masks at the border, pad channels as poison)."""
+    rng = np.random.default_rng(20240928)
+    for case in range(60 if be.name == 'emu' else 80):
+        B, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(1, 12))
+        k = int(rng.choice([1, 3]))
+        Cin = int(rng.choice([3, 16, 19, 33, 64, 70, 96, 131]))
+        Cout = int(rng.choice([5, 14, 32, 42, 65, 78, 96, 128, 131]))
+        Ts = [64, 128] + ([96] if (k == 3 and 64 < Cin <= 96 and 64 < Cout <= 96) else [])    # the kernel-row variant serves 65..96 channels
+        T = int(rng.choice(Ts))
+        nsplit = int(rng.integers(1, 9))
+        masked = bool(rng.random() < 0.3)
+        x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+        g = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
+        mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if masked else None
+        dw = be.wgrad(x, g, k, T, nsplit, mask, -0.25)
+        xz = x.astype(np.float64)
+        if masked:
+            xz = xz * (~(mask.reshape(B, H, W, 1) < -0.25))
+        pad = k // 2
+        xp = np.pad(xz, ((0, 0), (pad, pad), (pad, pad), (0, 0)))
+        ref = np.zeros((k, k, Cin, Cout))
+        for dy in range(k):
+            for dx in range(k):
+                ref[dy, dx] = np.einsum('bhwc,bhwd->cd', xp[:, dy:dy + H, dx:dx + W], g.astype(np.float64))
+        assert np.abs(dw - ref).max() / (np.abs(ref).max() + 1e-12) < 2e-5, (case, B, H, W, Cin, Cout, k, T, nsplit, masked)
+
+
 @pytest.mark.parametrize('case', [c for c in WGRAD_CASES if c[6] != 96], ids=lambda c: 'x'.join(map(str, c[:8])))
 def test_wgrad_bf16_kernel_direct(be, case):
     """conv_wgrad_bf16_kernel (v_mfma_f32_32x32x16_bf16 over pixel-contiguous, register-transposed tiles): the fp64

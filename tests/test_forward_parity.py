@@ -391,6 +391,40 @@ def test_vote_crafted_cases(be):
     h.close()
 
 
+def test_vote_seeded_random_maps(be):
+    """The vote kernel on seeded random maps (smooth bumps + noise, a third of the pixels background, cameras and centres of mass
+    in the range of the synthetic crops) against the oracle's _xyz_estimation: top-5 selection, re-projection weights,
+    4x4x4 start cell and ten mean-shift iterations, in mm."""
+    from oracle.graph import NetConfig
+    from oracle import pose
+    rng = np.random.default_rng(314159)
+    B, m, J = 4, 32, 7
+    yy, xx = np.mgrid[0:m, 0:m].astype(np.float32)
+    for rep in range(3):
+        hm = 0.05 * rng.standard_normal((B, m, m, J)).astype(np.float32)
+        hm3 = np.abs(0.05 * rng.standard_normal((B, m, m, J))).astype(np.float32)
+        for b in range(B):
+            for j in range(J):
+                for _ in range(int(rng.integers(1, 4))):                      # a few bumps per joint map
+                    cy, cx, a = rng.uniform(3, m - 3), rng.uniform(3, m - 3), rng.uniform(0.3, 1.0)
+                    bump = (a * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * rng.uniform(1.0, 3.0) ** 2))).astype(np.float32)
+                    hm[b, :, :, j] += bump
+                    hm3[b, :, :, j] += bump * np.float32(rng.uniform(0.5, 1.0))
+        um = (0.3 * rng.standard_normal((B, m, m, 3 * J))).astype(np.float32)
+        tiny = rng.uniform(-0.4, 0.9, (B, m, m, 1)).astype(np.float32)
+        tiny[rng.random((B, m, m, 1)) < 0.33] = -1.0                          # background
+        ndm = np.repeat(np.repeat(tiny, 4, axis=1), 4, axis=2).astype(np.float32)
+        cfg = np.stack([[rng.uniform(380, 720), rng.uniform(380, 720), 64 + rng.normal(0, 3), 64 + rng.normal(0, 3), 128, 128]
+                        for _ in range(B)]).astype(np.float32)
+        com = np.stack([[rng.normal(0, 40), rng.normal(0, 40), rng.uniform(250, 900)] for _ in range(B)]).astype(np.float32)
+        want = pose.estimate_pose_mm(hm, hm3, um, ndm, cfg, com)
+        h = be.handle(NetConfig(1, 8, J), B)
+        xyz = be.vote(h, hm, hm3, um, ndm, cfg, com)
+        h.close()
+        assert np.isfinite(xyz).all()
+        np.testing.assert_allclose(xyz, want, atol=5e-3, rtol=0, err_msg='rep %d' % rep)
+
+
 def test_abi_error_behaviour(be):
     """Argument checking mirrors the reference's error behaviour (ValueError on unknown input size,
     um_v1.py:106-107) plus the C-ABI contract of SURVEY 8b."""

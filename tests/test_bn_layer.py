@@ -208,6 +208,26 @@ def test_bias_conv_backward_from_the_readers_dgrad(be):
         np.testing.assert_allclose(be.host(d_b) - 0.5, g_ref.sum((0, 1, 2)), rtol=1e-5, atol=1e-5 * np.abs(g_ref).sum((0, 1, 2)).max())
 
 
+def test_bn_layer_seeded_sweep(be):
+    """Seeded random layers through dr_dbg_bn_layer against the fp64 autograd (1e-5 of each tensor's max, as above): odd image
+    sides, ragged channel counts, 1x1 and 3x3, with / without ReLU and residual, own reduce pass or sums from a consumer's dgrad
+    (single reader or last writer), row counts on both sides of the fused-fold threshold."""
+    rng = np.random.default_rng(777)
+    n = 10 if be.name == 'emu' else 24
+    for i in range(n):
+        big = be.name == 'gpu' or i % 5 == 0                          # some layers beyond 48 partial rows (finalize launch)
+        B = int(rng.integers(1, 5))
+        H, W = (int(rng.integers(20, 40)), int(rng.integers(20, 40))) if big else (int(rng.integers(1, 10)), int(rng.integers(1, 10)))
+        Cin = int(rng.choice([3, 16, 19, 40, 64]))
+        Cout = int(rng.choice([5, 14, 33, 65, 78, 128, 131]))
+        k = int(rng.choice([1, 3]))
+        relu = bool(rng.random() < 0.7)
+        with_res = bool(rng.random() < 0.3)
+        mode = int(rng.integers(0, 3))                                # 0 own reduce, 1 consumer dgrad, 2 consumer as the last writer
+        consumer = None if mode == 0 else (int(rng.choice([1, 3])), int(rng.choice([8, 33, 64])))
+        _run(be, B, H, W, Cin, Cout, k, relu=relu, with_res=with_res, consumer=consumer, both=(mode == 2), seed=1000 + i)
+
+
 def test_bn_layer_lookback_handoff_opt_in(be, monkeypatch):
     """DR_BN_LOOKBACK=1 (opt-in; measured slower on MI355X, kept correct): the apply launches carry producer workgroups that
     fold the partial rows and hand the coefficients to the streaming workgroups behind a counter, no finalize launch."""

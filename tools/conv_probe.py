@@ -1,6 +1,10 @@
 #!/usr/bin/env python
 """One-off conv micro-benchmarks: python tools/conv_probe.py HW:Cin:Cout:k[:tile[:abl]] ...   (B=40, 30 launches each).
-tile: -1 heuristic, 0 128x128, 1 64x128, 2 128x64, 3 64x64, 4 128x32, 5 64x64 BK64, 7 64x96, 8 64x160; abl: conv_igemm.h ABL."""
+tile: -1 heuristic, 0 128x128, 1 64x128, 2 128x64, 3 64x64, 4 128x32, 5 64x64 BK64, 6 split-K 32x32, 7 64x96, 8 64x160.
+abl (dr_dbg_conv_bench; 0 = product kernel of the given tile): 1-3 the 128x128 tile without refill / with VALU instead of MFMA /
+without epilogue stores; 5 product kernel + residual add; 6 all-zero operands; on the 64x128 tile: 7 no refill, 8 refill loads
+without LDS writes, 9 LDS writes without loads, 10 = 7 without the barrier, 11 = 7 without fragment reads, 12 = neither (the bare
+MFMA loop), 13 = 12 without epilogue stores."""
 import ctypes as C
 import os
 import sys

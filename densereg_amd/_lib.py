@@ -10,6 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libdensereg_hip.so')
+DEBUG_LIB_PATH = os.path.join(_HERE, 'lib', 'libdensereg_hip_dbg.so')      # product sources + dr_dbg_* hooks (tests/, tools/)
 
 DR_OK = 0
 DROPOUT_OFF, DROPOUT_MASK, DROPOUT_RNG = 0, 1, 2
@@ -81,7 +82,15 @@ SIGNATURES = {
     'dr_crop_from_pose': (_i, [_i, _vp, _i, _i, _vp, _i, _vp, _i, C.c_float, _i, _vp, _vp, _vp, _vp]),
     'dr_crop_from_bbx': (_i, [_i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'dr_data_aug': (_i, [_i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    # include/densereg_debug.h (test hooks)
+    'dr_profile_enable': (_i, [_vp, _i]),
+    'dr_profile_read': (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
+    'dr_profile_detail': (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
+    'dr_lookback_expired': (_i, [_vp]),        # diagnostic of the opt-in BatchReNorm look-back (DR_BN_LOOKBACK=1)
+}
+
+# include/densereg_debug.h: test / micro-benchmark hooks.  NOT in the product library: libdensereg_hip_dbg.so (same sources
+# + -DDR_DEBUG_HOOKS) and the host emulator export them; tests/ and tools/ load that library for these calls only.
+DEBUG_SIGNATURES = {
     'dr_dbg_conv_bench': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
     'dr_dbg_force_tile': (_i, [_i]),
     'dr_dbg_force_bf16': (_i, [_i]),
@@ -91,18 +100,15 @@ SIGNATURES = {
     'dr_dbg_wgrad': (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, C.c_float, _i, _i, _vp, _vp]),
     'dr_dbg_mfma_peak': (_i, [_i, _i, _i, C.POINTER(C.c_float)]),
     'dr_dbg_bn_layer': (_i, [C.POINTER(DbgBnArgs), _vp]),
-    'dr_dbg_lookback_expired': (_i, [_vp]),
     'dr_dbg_maxpool': (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     'dr_dbg_act_dgrad': (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, C.c_float, _vp, _vp, _vp]),
-    'dr_profile_enable': (_i, [_vp, _i]),
-    'dr_profile_read': (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
-    'dr_profile_detail': (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
     'dr_dbg_conv2d': (_i, [_i, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _fp, C.c_float, _fp, _i, _fp, _vp]),
 }
 
 
-def bind(lib: C.CDLL) -> C.CDLL:
-    for name, (res, args) in SIGNATURES.items():
+def bind(lib: C.CDLL, debug: bool = False) -> C.CDLL:
+    sigs = dict(SIGNATURES, **DEBUG_SIGNATURES) if debug else SIGNATURES
+    for name, (res, args) in sigs.items():
         fn = getattr(lib, name)          # AttributeError if the library misses a declared symbol
         fn.restype = res
         fn.argtypes = args
@@ -124,6 +130,22 @@ def load() -> C.CDLL:
         if _lib.dr_backend() != b'hip-gfx950':
             raise ImportError('densereg_amd: %s is not the HIP build (backend=%r)' % (LIB_PATH, _lib.dr_backend()))
     return _lib
+
+
+_dbg = None
+
+
+def load_debug() -> C.CDLL:
+    """The debug build (``libdensereg_hip_dbg.so``: the product's sources + the ``dr_dbg_*`` hooks of
+    ``include/densereg_debug.h``).  Only tests/ and tools/ call this; nothing in the package does."""
+    global _dbg
+    if _dbg is None:
+        if not os.path.exists(DEBUG_LIB_PATH):
+            raise ImportError('densereg_amd: %s not found (./build.sh builds it next to the product library)' % DEBUG_LIB_PATH)
+        _dbg = bind(C.CDLL(DEBUG_LIB_PATH), debug=True)
+        if _dbg.dr_backend() != b'hip-gfx950':
+            raise ImportError('densereg_amd: %s is not the HIP build' % DEBUG_LIB_PATH)
+    return _dbg
 
 
 class Handle:

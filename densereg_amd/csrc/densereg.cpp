@@ -55,8 +55,11 @@ template <int BM, int BN, int WM, int WN, int BK = 16, int GL = 0, int BF = 0, i
 static void launch_cfg(const ConvParams& p_in, hipStream_t s) {
     // N blocks of a row block back to back in dispatch order (conv_igemm.h nfast); DR_CONV_NFAST=0: plain 2-D grid order
     static const int nfast = [] { const char* e = getenv("DR_CONV_NFAST"); return (e && e[0] == '0') ? 0 : 1; }();
+    // static per-workgroup wave priorities (conv_igemm.h, ConvParams::prio): DR_CONV_PRIO = 0 off, 1..4 the assignment
+    static const int prio = [] { const char* e = getenv("DR_CONV_PRIO"); return e ? atoi(e) : 0; }();
     ConvParams p = p_in;
     p.nfast = nfast;
+    p.prio = prio;
     const int M = p.B * p.H * p.W;
     dim3 grid(dr_ceil_div(M, BM), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, BN));
     p.gx = (int)grid.x; p.gy = (int)grid.y;
@@ -96,7 +99,9 @@ int conv_tile_id(const ConvParams& p) {
     // Below ~128 such workgroups (8x8 pixels and smaller at B = 40) even that leaves most of the chip idle while each wave
     // issues the whole K axis: the split-K kernel (conv_splitk.h) quarters the chain and quadruples the workgroups
     // (profiles/r01_conv_small_layers.md: 3x3 64->64 at 8x8 18.7 -> 10.9 us, 1x1 128->64 7.5 -> 5.5 us; at 16x16 it loses).
-    if (rows64 * dr_ceil_div(ncols, 64) <= 128 && (long)p.ksize * p.ksize * dr_ceil_div(p.Kp, p.bf16 ? 32 : 16) >= 4) return KID_CONV_SPLITK;
+    // (an input STORED as bf16 stays on the tiled kernels: the split-K kernel stages fp32 only -- a mispredicted storage decision
+    // upstream then costs speed, not a failed launch)
+    if (!p.x_bf16 && rows64 * dr_ceil_div(ncols, 64) <= 128 && (long)p.ksize * p.ksize * dr_ceil_div(p.Kp, p.bf16 ? 32 : 16) >= 4) return KID_CONV_SPLITK;
     if (!p.bf16 && ncols % 64 == 0 && rows64 * (ncols / 64) <= 256 && (long)p.ksize * p.ksize * p.Kp >= 128) return KID_CONV_64x64_K64;
     if (ncols % 128 == 0) {
         const long b128 = rows128 * (ncols / 128), b64x128 = rows64 * (ncols / 128), b64x64 = rows64 * (ncols / 64);
@@ -1260,200 +1265,16 @@ double dr_conv_flops_per_crop(const dr_handle* h) { return h ? h->flops_per_crop
 #include "train_exec.inc"
 
 // ==============================================================================================
-// test hooks (include/densereg_debug.h)
+// test hooks (include/densereg_debug.h): compiled into libdensereg_hip_dbg.so and the emulator build only
 // ==============================================================================================
+#include "../../include/densereg_profile.h"
+#if defined(DR_DEBUG_HOOKS)
 #include "../../include/densereg_debug.h"
-extern "C" int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, const float* x, int x_cs, const float* w,
-                             const float* scale, const float* shift, int relu, const float* res, int res_cs,
-                             const float* rowmask, float thresh, float* y, int y_cs, double* stat, dr_stream stream) {
-    if (!x || !w || !y || (k != 1 && k != 3)) return DR_E_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    const int taps = k * k, Kp = dr_round_up(Cin, g_dbg_bf16 ? 32 : 16), Np = dr_round_up(Cout, 32);
-    float* wp = (float*)rt::dmalloc((size_t)taps * Kp * Np * sizeof(float));
-    if (!wp) return DR_E_NOMEM;
-    if (g_dbg_bf16) DR_LAUNCH(pack_weights_bf16_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, w, (__bf16*)wp, taps, Cin, Cout, Kp, Np);
-    else DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, w, wp, taps, Cin, Cout, Kp, Np);
-    ConvParams p{};
-    p.bf16 = g_dbg_bf16;
-    p.x_bf16 = (g_dbg_bf16 && g_dbg_bf16_storage) ? 1 : 0;
-    p.x = x; p.x_cs = x_cs; p.x_coff = 0; p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.ksize = k;
-    p.w = wp; p.Kp = Kp; p.Np = Np; p.y = y; p.y_cs = y_cs; p.y_coff = 0; p.Cout = Cout;
-    p.scale = scale; p.shift = shift; p.relu = relu; p.res = res; p.res_cs = res_cs; p.res_coff = 0;
-    p.rowmask = rowmask; p.mask_thresh = thresh;
-    double* part = nullptr;
-    if (stat) {
-        part = (double*)rt::dmalloc((size_t)dr_ceil_div(B * H * W, 32) * 2 * Cout * sizeof(double));   // 32-row tiles at most
-        if (!part) return DR_E_NOMEM;
-        p.stat_part = part;
-    }
-    float* zeros = (float*)rt::dmalloc(256);
-    if (!zeros) return DR_E_NOMEM;
-    rt::memset_async(zeros, 0, 256, s);
-    p.zeros = zeros;
-    int rc = launch_conv_igemm(p, s);
-    if (!rc && stat) DR_LAUNCH(stat_fold_kernel, dim3(dr_ceil_div(Cout, 4)), dim3(256), 0, s, (const double*)part, conv_stat_rows(p), Cout, stat);
-    rt::sync_stream(s);
-    rt::dfree(wp);
-    rt::dfree(zeros);
-    if (part) rt::dfree(part);
-    std::string m;
-    if (rc || rt::last_error(&m)) return DR_E_DEVICE;
-    return DR_OK;
-}
+#include "debug_hooks.inc"
+#endif
 
-// Weight gradient of one conv on caller buffers: dw[k][k][Cin][Cout] = sum_pixels x(shifted) * g.  T = 64 / 128
-// picks the tile, nsplit the number of pixel-axis slabs (folded by wgrad_reduce_kernel), as the executor does.
-extern "C" int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const float* x, int x_cs, const float* g, int g_cs,
-                            const float* rowmask, float thresh, int T, int nsplit, float* dw, dr_stream stream) {
-    if (!x || !g || !dw || (k != 1 && k != 3) || (T != 64 && T != 128 && T != 96) || nsplit < 1) return DR_E_INVALID;
-    if (T == 96 && (k != 3 || Cin > 96 || Cout > 96 || Cin <= 64 || Cout <= 64)) return DR_E_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    const int taps = k * k;
-    const long M = (long)B * H * W;
-    const size_t per = (size_t)taps * Cin * Cout;
-    const int rows = dr_round_up((int)((M + nsplit - 1) / nsplit), 16);
-    nsplit = (int)((M + rows - 1) / rows);
-    float* partial = (float*)rt::dmalloc((size_t)nsplit * per * sizeof(float));
-    if (!partial) return DR_E_NOMEM;
-    WgradParams p{};
-    p.x = x; p.x_cs = x_cs; p.Cin = Cin; p.g = g; p.g_cs = g_cs; p.Cout = Cout;
-    p.B = B; p.H = H; p.W = W; p.ksize = k; p.rowmask = rowmask; p.mask_thresh = thresh;
-    p.partial = partial; p.nsplit = nsplit; p.rows_per_split = rows;
-    p.g_bf16 = (g_dbg_bf16 && g_dbg_bf16_storage) ? 1 : 0;
-    p.x_bf16 = p.g_bf16;
-    dim3 grid(dr_ceil_div(Cin, T) * dr_ceil_div(Cout, T) * taps * nsplit);
-    if (g_dbg_bf16 && T == 128) launch_wgrad_bf16(p, 128, grid, s);
-    else if (g_dbg_bf16 && T == 64) launch_wgrad_bf16(p, 64, grid, s);
-    else if (T == 96) DR_LAUNCH(conv_wgrad_row_kernel, dim3(3 * nsplit), dim3(256), 0, s, p);
-    else if (T == 128) DR_LAUNCH((conv_wgrad_kernel<128>), grid, dim3(256), 0, s, p);
-    else DR_LAUNCH((conv_wgrad_kernel<64>), grid, dim3(256), 0, s, p);
-    rt::memset_async(dw, 0, per * sizeof(float), s);
-    DR_LAUNCH(wgrad_reduce_kernel, dim3(grid_for((long)per, 64)), dim3(256), 0, s, (const float*)partial, nsplit, (long)per, dw);
-    rt::sync_stream(s);
-    rt::dfree(partial);
-    std::string m;
-    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
-}
-
-// One conv -> BatchReNorm(train) layer, forward + backward, with the executors' launch logic (densereg_debug.h).
-extern "C" int dr_dbg_bn_layer(dr_dbg_bn_args* a, dr_stream stream) {
-    if (!a || !a->x || !a->w || !a->gamma || !a->beta || !a->mm || !a->mv || !a->y || !a->raw || !a->bnc || !a->mm_next ||
-        !a->mv_next || !a->draw || !a->dgamma || !a->dbeta || !a->dout_used)
-        return DR_E_INVALID;
-    if ((a->k != 1 && a->k != 3) || (!a->dout && !(a->gr && a->wr && (a->kr == 1 || a->kr == 3) && a->Cr > 0))) return DR_E_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    const int C = a->Cout, cs = dr_round_up(C, 4), taps = a->k * a->k;
-    const long M = (long)a->B * a->H * a->W;
-    const int Kp = dr_round_up(a->Cin, 16), Np = dr_round_up(C, 32);
-    std::vector<void*> tmp;
-    auto alloc = [&](size_t bytes) { void* q = rt::dmalloc(std::max<size_t>(bytes, 16)); tmp.push_back(q); return q; };
-    float* wp = (float*)alloc((size_t)taps * Kp * Np * 4);
-    float* zeros = (float*)alloc(256);
-    float* small = (float*)alloc((size_t)(2 + 2 + 3) * C * 4);           // scale|shift, shadow mean|var, coef[3]
-    double* part = (double*)alloc((size_t)std::max<long>((M + 31) / 32, 1024) * 2 * C * 8);
-    double* part2 = (double*)alloc((size_t)std::max<long>((M + 31) / 32, 1024) * 2 * C * 8);
-    int* flags = (int*)alloc(64);
-    const char* lb_env = getenv("DR_BN_LOOKBACK");
-    const bool lookback = lb_env && lb_env[0] == '1';
-    bool ok = true;
-    for (void* q : tmp) ok = ok && q;
-    float* wpT = nullptr;
-    int KpT = 0, NpT = 0;
-    const bool consumer = a->gr && a->wr && (a->kr == 1 || a->kr == 3) && a->Cr > 0;
-    if (ok && consumer) {
-        KpT = dr_round_up(a->Cr, 16); NpT = dr_round_up(C, 32);
-        wpT = (float*)alloc((size_t)a->kr * a->kr * KpT * NpT * 4);
-        ok = ok && wpT;
-    }
-    auto cleanup = [&]() { for (void* q : tmp) if (q) rt::dfree(q); };
-    if (!ok) { cleanup(); return DR_E_NOMEM; }
-    rt::memset_async(zeros, 0, 256, s);
-    rt::memset_async(flags, 0, 64, s);
-    rt::memset_async(small, 0, (size_t)7 * C * 4, s);
-    rt::memset_async(a->dgamma, 0, (size_t)C * 4, s);
-    rt::memset_async(a->dbeta, 0, (size_t)C * 4, s);
-    float* scale = small; float* shift = small + C;
-    // ---- forward: run_conv_train ---------------------------------------------------------------
-    DR_LAUNCH(pack_weights_kernel, dim3(grid_for((long)taps * Kp * Np)), dim3(256), 0, s, a->w, wp, taps, a->Cin, C, Kp, Np);
-    ConvParams p{};
-    p.x = a->x; p.x_cs = a->x_cs; p.Cin = a->Cin; p.B = a->B; p.H = a->H; p.W = a->W; p.ksize = a->k;
-    p.w = wp; p.Kp = Kp; p.Np = Np; p.y = a->raw; p.y_cs = cs; p.Cout = C; p.stat_part = part; p.zeros = zeros;
-    a->fwd_rows = conv_stat_rows(p);
-    int rc = launch_conv_igemm(p, s);
-    BnTrainParams fp{};
-    fp.raw = a->raw; fp.raw_cs = cs; fp.M = M; fp.C = C; fp.part = part; fp.part_rows = a->fwd_rows;
-    fp.beta = a->beta; fp.gamma = a->gamma; fp.mm = a->mm; fp.mv = a->mv; fp.mm_next = a->mm_next; fp.mv_next = a->mv_next;
-    fp.shadow_mean = small + 2 * C; fp.shadow_var = small + 3 * C; fp.shadow_step = 1;
-    fp.r_max = a->r_max; fp.d_max = a->d_max; fp.eps = 0.001f; fp.decay = 0.99f;
-    fp.scale = scale; fp.shift = shift; fp.bnc = a->bnc; fp.relu = a->relu ? 1 : 0;
-    fp.res = View{nullptr, 0, 0, 0};
-    if (a->res) fp.res = View{const_cast<float*>(a->res), cs, 0, C};
-    fp.out = View{a->y, cs, 0, C};
-    fp.out_bf16 = (g_dbg_bf16_storage && !a->res) ? 1 : 0;
-    const int rpb = 256 / (cs / 4);
-    if (!rc) {
-        if (fp.part_rows <= kBnFuseRows) {
-            DR_LAUNCH(bn_train_apply_kernel<1>, dim3(grid_for(M, rpb, bn_grid_cap())), dim3(256), 0, s, fp);
-        } else if (lookback) {
-            fp.flag = flags; fp.flag_target = dr_ceil_div(C, 4);
-            DR_LAUNCH(bn_train_apply_kernel<2>, dim3(grid_for(M, rpb, bn_grid_cap()) + dr_ceil_div(C, 4)), dim3(256), 0, s, fp);
-        } else {
-            DR_LAUNCH(bn_fwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, s, fp);
-            DR_LAUNCH(bn_train_apply_kernel<0>, dim3(grid_for(M, rpb, bn_grid_cap())), dim3(256), 0, s, fp);
-        }
-    }
-    // ---- backward: backward_conv (BatchReNorm part) ------------------------------------------------
-    BnBwdParams bp{};
-    bp.raw = a->raw; bp.raw_cs = cs; bp.M = M; bp.C = C; bp.relu = a->relu ? 1 : 0;
-    bp.scale = scale; bp.shift = shift; bp.bnc = a->bnc; bp.gamma = a->gamma;
-    bp.coef = small + 4 * C; bp.dbeta = a->dbeta; bp.dgamma = a->dgamma; bp.draw = a->draw;
-    bp.draw_bf16 = g_dbg_bf16_storage ? 1 : 0;
-    if (a->res && a->dres) { bp.dres = View{a->dres, cs, 0, C}; bp.dres_acc = 0; }
-    if (!rc && !consumer) {
-        rt::d2d(a->dout_used, a->dout, (size_t)M * cs * 4, s);
-        bp.dout = View{a->dout_used, cs, 0, C};
-        bp.part = part; bp.part_rows = grid_for(M, rpb * 8, 256);
-        DR_LAUNCH(bn_bwd_reduce_kernel, dim3(bp.part_rows), dim3(256), 0, s, bp);
-    } else if (!rc) {
-        const int tr = a->kr * a->kr;
-        DR_LAUNCH(pack_weights_T_kernel, dim3(grid_for((long)tr * KpT * NpT)), dim3(256), 0, s, a->wr, wpT, tr, C, a->Cr, KpT, NpT);
-        ConvParams q{};
-        q.x = a->gr; q.x_cs = a->gr_cs; q.Cin = a->Cr; q.B = a->B; q.H = a->H; q.W = a->W; q.ksize = a->kr;
-        q.w = wpT; q.Kp = KpT; q.Np = NpT; q.y = a->dout_used; q.y_cs = cs; q.Cout = C; q.zeros = zeros;
-        if (a->dout) {                  // dOut already holds another reader's contribution: this dgrad is the LAST writer
-            rt::d2d(a->dout_used, a->dout, (size_t)M * cs * 4, s);
-            q.res = a->dout_used; q.res_cs = cs; q.res_coff = 0;
-        }
-        q.stat_part = part2; q.bst_raw = a->raw; q.bst_cs = cs; q.bst_relu = a->relu ? 1 : 0;
-        q.bst_scale = scale; q.bst_shift = shift; q.bst_bnc = a->bnc;
-        bp.dout = View{a->dout_used, cs, 0, C};
-        bp.part = part2; bp.part_rows = conv_stat_rows(q);
-        rc = launch_conv_igemm(q, s);
-    }
-    a->bwd_rows = bp.part_rows;
-    if (!rc) {
-        if (bp.part_rows <= kBnFuseRows) {
-            DR_LAUNCH(bn_bwd_apply_kernel<1>, dim3(grid_for(M, rpb, bn_grid_cap())), dim3(256), 0, s, bp);
-        } else if (lookback) {
-            bp.flag = flags + 2; bp.flag_target = dr_ceil_div(C, 4);
-            DR_LAUNCH(bn_bwd_apply_kernel<2>, dim3(grid_for(M, rpb, bn_grid_cap()) + dr_ceil_div(C, 4)), dim3(256), 0, s, bp);
-        } else {
-            DR_LAUNCH(bn_bwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, s, bp);
-            DR_LAUNCH(bn_bwd_apply_kernel<0>, dim3(grid_for(M, rpb, bn_grid_cap())), dim3(256), 0, s, bp);
-        }
-    }
-    rt::sync_stream(s);
-    int hflags[4] = {0, 0, 0, 0};
-    rt::d2h(hflags, flags, sizeof(hflags), s);
-    rt::sync_stream(s);
-    cleanup();
-    if (hflags[1] || hflags[3]) return DR_E_STATE;                     // a look-back wait expired
-    std::string m;
-    if (rc || rt::last_error(&m)) return DR_E_DEVICE;
-    return DR_OK;
-}
-
-extern "C" int dr_dbg_lookback_expired(dr_handle* h) {
+// diagnostic of the opt-in BatchReNorm look-back hand-off (DR_BN_LOOKBACK=1): bounded waits that ran out; 0 otherwise
+extern "C" int dr_lookback_expired(dr_handle* h) {
     if (!h || !h->bn_flags) return 0;
     rt::sync_stream(nullptr);
     std::vector<int> f(h->convs.size() * 4, 0);
@@ -1462,322 +1283,6 @@ extern "C" int dr_dbg_lookback_expired(dr_handle* h) {
     int n = 0;
     for (size_t i = 0; i < h->convs.size(); ++i) n += f[4 * i + 1] + f[4 * i + 3];
     return n;
-}
-
-extern "C" int dr_dbg_act_dgrad(int B, int H, int W, int C, int Cr, int kr, const float* out, const float* gr, int gr_cs,
-                                const float* wr, float factor, float* g, float* dbias, dr_stream stream) {
-    if (!out || !gr || !wr || !g || !dbias || (kr != 1 && kr != 3) || C < 1 || Cr < 1) return DR_E_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    const int cs = dr_round_up(C, 4), tr = kr * kr, KpT = dr_round_up(Cr, 16), NpT = dr_round_up(C, 32);
-    const long M = (long)B * H * W;
-    float* wpT = (float*)rt::dmalloc((size_t)tr * KpT * NpT * 4);
-    float* zeros = (float*)rt::dmalloc(256);
-    double* part = (double*)rt::dmalloc((size_t)std::max<long>((M + 31) / 32, 1024) * 2 * C * 8);
-    if (!wpT || !zeros || !part) return DR_E_NOMEM;
-    rt::memset_async(zeros, 0, 256, s);
-    DR_LAUNCH(pack_weights_T_kernel, dim3(grid_for((long)tr * KpT * NpT)), dim3(256), 0, s, wr, wpT, tr, C, Cr, KpT, NpT);
-    ConvParams q{};
-    q.x = gr; q.x_cs = gr_cs; q.Cin = Cr; q.B = B; q.H = H; q.W = W; q.ksize = kr;
-    q.w = wpT; q.Kp = KpT; q.Np = NpT; q.y = g; q.y_cs = cs; q.Cout = C; q.zeros = zeros;
-    q.stat_part = part; q.bst_raw = out; q.bst_cs = cs; q.bst_relu = 1; q.bst_act = 1; q.bst_factor = factor;
-    const int rows = conv_stat_rows(q);
-    int rc = launch_conv_igemm(q, s);
-    if (!rc) DR_LAUNCH(bias_grad_from_rows_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, s, (const double*)part, rows, C, dbias);
-    rt::sync_stream(s);
-    rt::dfree(wpT); rt::dfree(zeros); rt::dfree(part);
-    std::string m;
-    return (rc || rt::last_error(&m)) ? DR_E_DEVICE : DR_OK;
-}
-
-// Max-pool k x k / stride 2 (TF 'SAME') forward with the recorded arg-max and its gather backward on dense [B][H][W][C]
-// device buffers (C % 4 == 0): y, then dx = (acc ? dx : 0) + the gradient dy routed to the first maximum of every window.
-extern "C" int dr_dbg_maxpool(int B, int H, int W, int C, int k, const float* x, float* y, const float* dy, float* dx, int acc,
-                              dr_stream stream) {
-    if (!x || !y || !dy || !dx || (k != 2 && k != 3) || C < 4 || C % 4 || B < 1 || H < 1 || W < 1) return DR_E_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    const int total = std::max((Ho - 1) * 2 + k - H, 0);
-    unsigned char* arg = (unsigned char*)rt::dmalloc((size_t)B * Ho * Wo * C);
-    if (!arg) return DR_E_NOMEM;
-    DR_LAUNCH(maxpool_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(256), 0, s, x, C, 0, B, H, W, C, k, total / 2, total / 2, y, C, 0,
-              Ho, Wo, arg);
-    DR_LAUNCH(maxpool_bwd_kernel, dim3(grid_for((long)B * H * W * (C / 4))), dim3(256), 0, s, (const unsigned char*)arg, dx, C, 0, B, H, W, C, k,
-              total / 2, total / 2, dy, C, 0, Ho, Wo, acc ? 1 : 0);
-    rt::sync_stream(s);
-    rt::dfree(arg);
-    std::string m;
-    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
-}
-
-// Micro-benchmark of the weight-gradient kernel + slab fold on self-allocated buffers: microseconds per call for a
-// given channel tile T and slab count nsplit (0 = the executor's planner).
-extern "C" int dr_dbg_wgrad_bench(int B, int H, int W, int Cin, int Cout, int k, int T, int nsplit, int iters, float* us_out,
-                                  int* nsplit_used) {
-    if (!us_out || iters < 1 || (k != 1 && k != 3)) return DR_E_INVALID;
-    ConvLayer c;
-    c.k = k; c.cin = Cin; c.cout = Cout; c.H = H; c.W = W;
-    WgradPlan wp = wgrad_plan(c, B);
-    if (T == 64 || T == 128 || (T == 96 && k == 3 && Cin <= 96 && Cout <= 96 && Cin > 64 && Cout > 64)) wp.T = T;
-    const int taps = k * k;
-    const long M = (long)B * H * W;
-    const size_t per = (size_t)taps * Cin * Cout;
-    if (nsplit > 0) {
-        const int rows = dr_round_up((int)((M + nsplit - 1) / nsplit), 16);
-        wp.nsplit = (int)((M + rows - 1) / rows); wp.rows_per_split = rows;
-    }
-    if (nsplit_used) *nsplit_used = wp.nsplit;
-    const int xcs = dr_round_up(Cin, 4), gcs = dr_round_up(Cout, 4);
-    float* x = (float*)rt::dmalloc(M * xcs * 4); float* g = (float*)rt::dmalloc(M * gcs * 4);
-    float* part = (float*)rt::dmalloc((size_t)wp.nsplit * per * 4); float* dw = (float*)rt::dmalloc(per * 4);
-    if (!x || !g || !part || !dw) return DR_E_NOMEM;
-    std::vector<float> hx((size_t)M * std::max(xcs, gcs));
-    unsigned st = 99u;
-    for (auto& v : hx) { st = st * 1664525u + 1013904223u; v = ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
-    rt::h2d(x, hx.data(), (size_t)M * xcs * 4, nullptr); rt::h2d(g, hx.data(), (size_t)M * gcs * 4, nullptr);
-    rt::memset_async(dw, 0, per * 4, nullptr);
-    rt::sync_stream(nullptr);
-    WgradParams p{};
-    p.x = x; p.x_cs = xcs; p.Cin = Cin; p.g = g; p.g_cs = gcs; p.Cout = Cout; p.B = B; p.H = H; p.W = W; p.ksize = k;
-    p.partial = part; p.nsplit = wp.nsplit; p.rows_per_split = wp.rows_per_split;
-    dim3 grid(dr_ceil_div(Cin, wp.T) * dr_ceil_div(Cout, wp.T) * taps * wp.nsplit);
-    auto launch = [&]() {
-        if (wp.T == 96) DR_LAUNCH(conv_wgrad_row_kernel, dim3(3 * wp.nsplit), dim3(256), 0, (hipStream_t) nullptr, p);
-        else if (wp.T == 128) DR_LAUNCH((conv_wgrad_kernel<128>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
-        else DR_LAUNCH((conv_wgrad_kernel<64>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
-        DR_LAUNCH(wgrad_reduce_kernel, dim3(grid_for((long)per, 64)), dim3(256), 0, (hipStream_t) nullptr, (const float*)part, wp.nsplit,
-                  (long)per, dw);
-    };
-    for (int i = 0; i < 3; ++i) launch();
-    rt::sync_stream(nullptr);
-    rt::Event a = rt::event_create(), b = rt::event_create();
-    rt::event_record(a, nullptr);
-    for (int i = 0; i < iters; ++i) launch();
-    rt::event_record(b, nullptr);
-    rt::sync_stream(nullptr);
-    *us_out = rt::event_elapsed_ms(a, b) * 1e3f / iters;
-    rt::event_destroy(a); rt::event_destroy(b);
-    for (void* q : {(void*)x, (void*)g, (void*)part, (void*)dw}) rt::dfree(q);
-    std::string m;
-    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
-}
-
-// Micro-benchmark of the three BatchReNorm streaming kernels on an [M][C] tensor: microseconds per launch of
-// (train apply, backward reduce, backward apply); `reduce_blocks` overrides the backward-reduce grid (0 = executor's).
-extern "C" int dr_dbg_bn_bench(long M, int C, int reduce_blocks, int iters, float* us_out) {
-    if (!us_out || M < 1 || C < 1 || C > 1024 || iters < 1) return DR_E_INVALID;
-    const int cs = dr_round_up(C, 4);
-    const size_t n = (size_t)M * cs;
-    float* raw = (float*)rt::dmalloc(n * 4); float* out = (float*)rt::dmalloc(n * 4); float* dout = (float*)rt::dmalloc(n * 4);
-    float* draw = (float*)rt::dmalloc(n * 4);
-    float* small = (float*)rt::dmalloc(16 * 1024 * 4);        // beta gamma mm mv mm_next mv_next scale shift bnc[4] shadow[2]
-    double* stats = (double*)rt::dmalloc(4 * 1024 * 8);
-    double* bpart = (double*)rt::dmalloc((size_t)2048 * 2 * 1024 * 8);
-    if (!raw || !out || !dout || !draw || !small || !stats || !bpart) return DR_E_NOMEM;
-
-    std::vector<float> hr(n), hs(16 * 1024, 1.0f);
-    unsigned st = 777u;
-    for (auto& v : hr) { st = st * 1664525u + 1013904223u; v = ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
-    rt::h2d(raw, hr.data(), n * 4, nullptr); rt::h2d(dout, hr.data(), n * 4, nullptr);
-    rt::h2d(small, hs.data(), hs.size() * 4, nullptr);
-    std::vector<double> hst(4 * 1024, 0.0);
-    for (int c = 0; c < C; ++c) { hst[c] = 0.1 * M; hst[C + c] = 0.5 * M; }       // one partial row: [2][C]
-    rt::h2d(stats, hst.data(), hst.size() * 8, nullptr);
-    rt::sync_stream(nullptr);
-    BnTrainParams fp{};
-    fp.raw = raw; fp.raw_cs = cs; fp.M = M; fp.C = C; fp.part = stats; fp.part_rows = 1;
-    fp.beta = small; fp.gamma = small + 1024; fp.mm = small + 2048; fp.mv = small + 3072;
-    fp.mm_next = small + 4096; fp.mv_next = small + 5120; fp.shadow_mean = small + 14336; fp.shadow_var = small + 15360; fp.shadow_step = 3;
-    fp.r_max = 3.f; fp.d_max = 5.f; fp.eps = 0.001f; fp.decay = 0.99f;
-    fp.scale = small + 6144; fp.shift = small + 7168; fp.bnc = small + 8192; fp.relu = 1;
-    fp.res = View{nullptr, 0, 0, 0}; fp.out = View{out, cs, 0, C};
-    BnBwdParams bp{};
-    bp.dout = View{dout, cs, 0, C}; bp.raw = raw; bp.raw_cs = cs; bp.M = M; bp.C = C; bp.relu = 1;
-    bp.scale = small + 6144; bp.shift = small + 7168; bp.bnc = small + 8192; bp.gamma = small + 1024;
-    bp.dbeta = small + 12288; bp.dgamma = small + 13312; bp.draw = draw; bp.coef = small + 9216;
-    const int rpb = 256 / (cs / 4);
-    const int g_apply = grid_for(M, rpb, bn_grid_cap());
-    const int g_reduce = reduce_blocks > 0 ? reduce_blocks : grid_for(M, rpb * 8, 256);
-    bp.part = bpart; bp.part_rows = g_reduce;
-    auto time_it = [&](int which) {
-        auto launch = [&]() {
-            if (which == 0) {
-                DR_LAUNCH(bn_fwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, (hipStream_t) nullptr, fp);
-                DR_LAUNCH(bn_train_apply_kernel<0>, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, fp);
-            } else if (which == 1) {
-                DR_LAUNCH(bn_bwd_reduce_kernel, dim3(g_reduce), dim3(256), 0, (hipStream_t) nullptr, bp);
-                DR_LAUNCH(bn_bwd_finalize_kernel, dim3(dr_ceil_div(C, 4)), dim3(256), 0, (hipStream_t) nullptr, bp);
-            } else {
-                DR_LAUNCH(bn_bwd_apply_kernel<0>, dim3(g_apply), dim3(256), 0, (hipStream_t) nullptr, bp);
-            }
-        };
-        for (int i = 0; i < 3; ++i) launch();
-        rt::sync_stream(nullptr);
-        rt::Event a = rt::event_create(), b = rt::event_create();
-        rt::event_record(a, nullptr);
-        for (int i = 0; i < iters; ++i) launch();
-        rt::event_record(b, nullptr);
-        rt::sync_stream(nullptr);
-        const float us = rt::event_elapsed_ms(a, b) * 1e3f / iters;
-        rt::event_destroy(a); rt::event_destroy(b);
-        return us;
-    };
-    for (int w = 0; w < 3; ++w) us_out[w] = time_it(w);
-    for (void* q : {(void*)raw, (void*)out, (void*)dout, (void*)draw, (void*)small, (void*)stats, (void*)bpart}) rt::dfree(q);
-    std::string m;
-    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
-}
-
-// Micro-benchmark of one conv shape: allocates its own buffers, `iters` launches timed with events.
-// tile: -1 heuristic, else a KernelId of a conv tile; abl: ablation variant of the 128x128 kernel.
-extern "C" int dr_dbg_conv_bench(int B, int H, int W, int Cin, int Cout, int k, int tile, int abl, int iters, float* ms_out) {
-    if (!ms_out || iters < 1 || (k != 1 && k != 3)) return DR_E_INVALID;
-    const int taps = k * k, Kp = dr_round_up(Cin, 16), Np = dr_round_up(Cout, 32);
-    const int x_cs = dr_round_up(Cin, 4), y_cs = dr_round_up(Cout, 4);
-    const size_t M = (size_t)B * H * W;
-    float* x = (float*)rt::dmalloc(M * x_cs * sizeof(float));
-    float* y = (float*)rt::dmalloc(M * y_cs * sizeof(float));
-    float* wp = (float*)rt::dmalloc((size_t)taps * (Kp + 32) * Np * sizeof(float));
-    float* sc = (float*)rt::dmalloc(Np * sizeof(float));
-    if (!x || !y || !wp || !sc) return DR_E_NOMEM;
-    // deterministic non-trivial fill (bit patterns of small floats)
-    std::vector<float> hx(M * x_cs), hw((size_t)taps * (Kp + 32) * Np), hs(Np, 1.0f);
-    unsigned st = 12345u;
-    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
-    for (auto& v : hx) v = abl == 6 ? 0.f : rnd();          // abl 6: all-zero operands (DVFS best case)
-    for (auto& v : hw) v = abl == 6 ? 0.f : rnd() * 0.05f;
-    const bool bf = g_dbg_bf16 && abl == 0;
-    if (bf) {                                               // the same buffer as bf16 elements: truncated small floats
-        uint16_t* hb = reinterpret_cast<uint16_t*>(hw.data());
-        for (size_t i = 0; i < hw.size() * 2; ++i) { const float f = rnd() * 0.05f; uint32_t u; memcpy(&u, &f, 4); hb[i] = (uint16_t)(u >> 16); }
-    }
-    rt::h2d(x, hx.data(), hx.size() * sizeof(float), nullptr);
-    rt::h2d(wp, hw.data(), hw.size() * sizeof(float), nullptr);
-    rt::h2d(sc, hs.data(), hs.size() * sizeof(float), nullptr);
-    rt::sync_stream(nullptr);
-    ConvParams p{};
-    p.x = x; p.x_cs = x_cs; p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.ksize = k;
-    p.w = wp; p.Kp = Kp; p.Np = Np; p.y = y; p.y_cs = y_cs; p.Cout = Cout; p.scale = sc; p.shift = sc; p.relu = 1;
-    if (bf) { p.bf16 = 1; p.Kp = dr_round_up(Cin, 32); }
-    float* zeros = (float*)rt::dmalloc(256);
-    if (!zeros) return DR_E_NOMEM;
-    rt::memset_async(zeros, 0, 256, nullptr);
-    p.zeros = zeros;
-    g_force_tile = tile;
-    float* res = nullptr;
-    if (abl == 5) {                                     // product kernel with a fused residual add
-        res = (float*)rt::dmalloc(M * y_cs * sizeof(float));
-        if (!res) return DR_E_NOMEM;
-        rt::memset_async(res, 0, M * y_cs * sizeof(float), nullptr);
-        p.res = res; p.res_cs = y_cs;
-    }
-    auto launch = [&]() {
-        const int Mi = (int)M;
-        if (abl > 0 && abl < 4) {
-            dim3 grid(dr_ceil_div(Mi, 128), dr_ceil_div(Np, 128));
-            p.gx = (int)grid.x; p.gy = (int)grid.y;
-            if (abl == 1) DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
-            else if (abl == 2) DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
-            else DR_LAUNCH((conv_igemm_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
-        } else if (abl == 7) {                         // 64x128 tile without refills: LDS reads + MFMA + barriers only
-            dim3 grid(dr_ceil_div(Mi, 64), dr_ceil_div(Np, 128));
-            p.gx = (int)grid.x; p.gy = (int)grid.y;
-            DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 1>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
-        } else if (abl == 13) {                        // 12 without the epilogue stores
-            dim3 grid(dr_ceil_div(Mi, 64), dr_ceil_div(Np, 128));
-            p.gx = (int)grid.x; p.gy = (int)grid.y;
-            DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 9>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
-        } else if (abl >= 10 && abl <= 12) {           // 64x128 tile, no refills, and: 10 no barrier / 11 no fragment reads / 12 neither
-            dim3 grid(dr_ceil_div(Mi, 64), dr_ceil_div(Np, 128));
-            p.gx = (int)grid.x; p.gy = (int)grid.y;
-            if (abl == 10) DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 6>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
-            else if (abl == 11) DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 7>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
-            else DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 8>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
-        } else if (abl == 8 || abl == 9) {             // 64x128 tile: refill loads without LDS writes / LDS writes without loads
-            dim3 grid(dr_ceil_div(Mi, 64), dr_ceil_div(Np, 128));
-            p.gx = (int)grid.x; p.gy = (int)grid.y;
-            if (abl == 8) DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 4>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
-            else DR_LAUNCH((conv_igemm_kernel<64, 128, 2, 2, 5>), grid, dim3(256), 0, (hipStream_t) nullptr, p);
-        } else {
-            launch_conv_igemm(p, nullptr);
-        }
-    };
-    for (int i = 0; i < 3; ++i) launch();
-    rt::sync_stream(nullptr);
-    rt::Event a = rt::event_create(), b = rt::event_create();
-    rt::event_record(a, nullptr);
-    for (int i = 0; i < iters; ++i) launch();
-    rt::event_record(b, nullptr);
-    rt::sync_stream(nullptr);
-    *ms_out = rt::event_elapsed_ms(a, b) / iters;
-    g_force_tile = -1;
-    rt::event_destroy(a); rt::event_destroy(b);
-    rt::dfree(x); rt::dfree(y); rt::dfree(wp); rt::dfree(sc); rt::dfree(zeros);
-    if (res) rt::dfree(res);
-    std::string m;
-    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
-}
-
-// Sustained fp32 MFMA rate of the chip (no memory traffic): every wave runs `iters` rounds of four independent
-// v_mfma_f32_32x32x2_f32 chains.  zero_data = 1 feeds zeros (the DVFS best case), 0 feeds varied values.
-// Documents the clock-limited ceiling under the nominal 157.3 TFLOP/s (profiles/*_conv_microbench.md).
-namespace dr {
-__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float seed, float* out) {
-    dr_f32x16 acc[4];
-    for (int j = 0; j < 4; ++j)
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    const float a = seed * (float)((threadIdx.x * 37 + blockIdx.x * 11) % 61 - 30);
-    const float b = seed * (float)((threadIdx.x * 13 + blockIdx.x * 7) % 53 - 26);
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
-    }
-    float s = 0.f;
-    for (int j = 0; j < 4; ++j)
-        for (int r = 0; r < 16; ++r) s += acc[j][r];
-    if (s == 12345.678f) out[0] = s;                   // keeps the chains alive, never true
-}
-}  // namespace dr
-
-extern "C" int dr_dbg_mfma_peak(int iters, int waves_per_simd, int zero_data, float* tflops_out) {
-    if (!tflops_out || iters < 1 || waves_per_simd < 1 || waves_per_simd > 8) return DR_E_INVALID;
-    float* out = (float*)rt::dmalloc(256);
-    if (!out) return DR_E_NOMEM;
-    const int blocks = 256 * waves_per_simd;           // one 4-wave block per CU per resident wave slot
-    const float seed = zero_data ? 0.f : 0.03125f;
-    for (int i = 0; i < 2; ++i) DR_LAUNCH(dr::mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t) nullptr, iters, seed, out);
-    rt::sync_stream(nullptr);
-    rt::Event a = rt::event_create(), b = rt::event_create();
-    rt::event_record(a, nullptr);
-    for (int i = 0; i < 5; ++i) DR_LAUNCH(dr::mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t) nullptr, iters, seed, out);
-    rt::event_record(b, nullptr);
-    rt::sync_stream(nullptr);
-    const double ms = rt::event_elapsed_ms(a, b) / 5;
-    const double flops = (double)blocks * 4 /*waves*/ * iters * 16 /*mfma*/ * (2.0 * 32 * 32 * 2);
-    *tflops_out = (float)(flops / (ms * 1e-3) / 1e12);
-    rt::event_destroy(a); rt::event_destroy(b);
-    rt::dfree(out);
-    std::string m;
-    return rt::last_error(&m) ? DR_E_DEVICE : DR_OK;
-}
-
-// force the conv tile choice of every following launch (-1 = heuristic); tests sweep all tile shapes with it
-extern "C" int dr_dbg_force_tile(int tile) {
-    if (tile < -1 || tile > KID_CONV_64x160) return DR_E_INVALID;
-    g_force_tile = tile;
-    return DR_OK;
-}
-
-// dr_dbg_conv2d and dr_dbg_conv_bench (abl 0) run the bf16 matrix-core kernels while on (process-global)
-extern "C" int dr_dbg_force_bf16_storage(int on) {
-    g_dbg_bf16_storage = on ? 1 : 0;
-    return DR_OK;
-}
-
-extern "C" int dr_dbg_force_bf16(int on) {
-    g_dbg_bf16 = on ? 1 : 0;
-    return DR_OK;
 }
 
 extern "C" int dr_profile_enable(dr_handle* h, int on) {

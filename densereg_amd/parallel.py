@@ -36,6 +36,14 @@ def check_world(num_gpus: int, world: int) -> None:
                          'or pass --num_gpus %d' % (num_gpus, world, num_gpus, world))
 
 
+def rank_seed(seed: int, rank: int, world: int) -> int:
+    """Dropout seed of one rank's micro-step.  Every tower of the reference builds its OWN dropout ops
+    (train_multi_gpu.py:63-90 calls the model once per tower; slim/ops.py:710-728 ``tf.nn.dropout`` draws an independent
+    mask per op), so two towers never drop the same units of the same micro-step.  The engine's keep bit is a stateless
+    function of (seed, layer, element): interleaving the ranks into the seed gives every (micro-step, rank) its own stream."""
+    return int(seed) * int(world) + int(rank)
+
+
 def decay_steps(dataset: str, batch_size: int, sub_batch: int) -> float:
     """hourglass_um_crop_tiny.py:109,174: (approximate_num / (batch*sub_batch)) * epochs_per_decay (a float).
     ``batch_size`` is the GLOBAL batch (all ranks together), as in the reference."""
@@ -58,6 +66,7 @@ class DataParallelTrainer:
         self.sub_batch = int(sub_batch)
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
         self._all_reduce = all_reduce            # injectable (gloo tests)
         self.micro = 0
         self.global_step = 0                     # optimizer steps applied so far
@@ -73,9 +82,10 @@ class DataParallelTrainer:
                 self.dist.all_reduce(self.flat_grad, op=self.dist.ReduceOp.SUM)
 
     def micro_step(self, dm_norm, pose_mm, cfg, com, seed: int = 0, dropout_mode: int = 2, keep_mask=None):
-        """One ``sess.run([accum_op, batchnorm_update_op, loss])`` (:146); returns the 4 loss terms (device)."""
+        """One ``sess.run([accum_op, batchnorm_update_op, loss])`` (:146); returns the 4 loss terms (device).
+        ``seed`` names the micro-step (the same on every rank); each rank drops its own units (``rank_seed``)."""
         eng = self.eng
-        eng.forward_train(dm_norm, dropout_mode, keep_mask, seed)
+        eng.forward_train(dm_norm, dropout_mode, keep_mask, rank_seed(seed, self.rank, self.world))
         losses = eng.loss(dm_norm, pose_mm, cfg, com)
         eng.backward(dm_norm.shape[0])
         self.micro += 1

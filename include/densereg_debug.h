@@ -1,5 +1,7 @@
-/* densereg_debug.h -- test hooks of libdensereg_hip.so.  NOT part of the integration surface:
- * they exist so that tests/ can drive a single kernel through the C ABI with raw pointers. */
+/* densereg_debug.h -- test / micro-benchmark hooks.  NOT part of the integration surface and NOT in the product library:
+ * libdensereg_hip_dbg.so (the product's sources built with -DDR_DEBUG_HOOKS) exports them so that tests/ and tools/ can drive
+ * a single kernel through a C entry point with raw pointers.  The product library libdensereg_hip.so exports densereg.h and
+ * densereg_profile.h only. */
 #ifndef DENSEREG_DEBUG_H_
 #define DENSEREG_DEBUG_H_
 #include "densereg.h"
@@ -72,10 +74,6 @@ int dr_dbg_act_dgrad(int B, int H, int W, int C, int Cr, int kr, const float* ou
 int dr_dbg_maxpool(int B, int H, int W, int C, int k, const float* x, float* y, const float* dy, float* dx, int acc,
                    dr_stream stream);
 
-/* Training handles: how many look-back waits of the BatchReNorm apply kernels expired so far (train_kernels.h: the wait is
- * bounded so that a scheduling surprise can never hang the device; it must stay 0).  Synchronises the device. */
-int dr_dbg_lookback_expired(dr_handle* h);
-
 /* Micro-benchmark one conv shape on self-allocated buffers: average milliseconds per launch.
  * tile = -1 (heuristic) or a tile id (0 128x128, 1 64x128, 2 128x64, 3 64x64, 4 128x32);
  * abl = 0 product kernel, 1/2/3 = ablations of the 128x128 kernel (no refills / no MFMA / no stores),
@@ -99,22 +97,6 @@ int dr_dbg_force_bf16_storage(int on);
 /* Force the conv tile of every following launch (-1 = heuristic; ids as in dr_dbg_conv_bench).
  * Process-global; tests use it to check every tile shape against the reference. */
 int dr_dbg_force_tile(int tile);
-
-/* Per-kernel timing with HIP events on the caller's stream (bench.py roofline leg).  While enabled,
- * every op of the executors is bracketed by two events; dr_profile_read synchronises, aggregates by
- * kernel, returns one row per kernel that ran, and resets.  flops/bytes are the ALGORITHMIC counts
- * (SURVEY 8d), not measured traffic. */
-typedef struct dr_kernel_stat {
-    char name[64];
-    int64_t launches;
-    double total_ms;
-    double flops;
-    double bytes;
-} dr_kernel_stat;
-int dr_profile_enable(dr_handle* h, int on);
-int dr_profile_read(dr_handle* h, dr_kernel_stat* out, int max_out, int* n_out);
-/* Same records, one row per (kernel, conv layer); call BEFORE dr_profile_read (which resets). */
-int dr_profile_detail(dr_handle* h, dr_kernel_stat* out, int max_out, int* n_out);
 
 #ifdef __cplusplus
 }

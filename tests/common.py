@@ -57,7 +57,7 @@ class Backend:
         d_res = None if res is None else self.dev(np.ascontiguousarray(res, np.float32))
         d_m = None if rowmask is None else self.dev(rowmask)
         d_st = self.dev(np.zeros((2, Cout), np.float64)) if want_stats else None
-        rc = self.lib.dr_dbg_conv2d(B, H, W, Cin, Cout, k, self.ptr(d_x), x_cs, self.ptr(d_w), self.ptr(d_sc),
+        rc = self.dbg.dr_dbg_conv2d(B, H, W, Cin, Cout, k, self.ptr(d_x), x_cs, self.ptr(d_w), self.ptr(d_sc),
                                     self.ptr(d_sh), int(relu), self.ptr(d_res), 0 if res is None else res.shape[-1],
                                     self.ptr(d_m), thresh, self.ptr(d_y), y_cs, self.ptr(d_st), self.stream)
         assert rc == 0, rc
@@ -78,7 +78,7 @@ class Backend:
         d_x, d_g = self.dev(xp), self.dev(gp)
         d_m = None if rowmask is None else self.dev(rowmask)
         d_w = self.dev(np.full((k, k, Cin, Cout), -777.0, np.float32))
-        rc = self.lib.dr_dbg_wgrad(B, H, W, Cin, Cout, k, self.ptr(d_x), x_cs, self.ptr(d_g), g_cs, self.ptr(d_m), thresh,
+        rc = self.dbg.dr_dbg_wgrad(B, H, W, Cin, Cout, k, self.ptr(d_x), x_cs, self.ptr(d_g), g_cs, self.ptr(d_m), thresh,
                                    T, nsplit, self.ptr(d_w), self.stream)
         assert rc == 0, rc
         self.sync()
@@ -128,6 +128,7 @@ class EmuBackend(Backend):
     def __init__(self):
         from tests.emu import load_emu
         self.lib = load_emu()
+        self.dbg = self.lib                 # the emulator build carries the dr_dbg_* hooks itself
 
     def dev(self, a):
         return np.ascontiguousarray(a).copy()
@@ -148,7 +149,8 @@ class GpuBackend(Backend):
     def __init__(self):
         import torch
         self.torch = torch
-        self.lib = _lib.load()
+        self.lib = _lib.load()              # the PRODUCT library: every handle of the GPU tests lives in it
+        self.dbg = _lib.load_debug()        # same sources + dr_dbg_* hooks: single-kernel entry points only
         self.device = torch.device('cuda', 0)
         self.stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

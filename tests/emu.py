@@ -37,7 +37,7 @@ def load_emu() -> C.CDLL:
     if _emu is None:
         if _stale():
             subprocess.check_call([os.path.join(ROOT, 'build.sh'), '--emu'], cwd=ROOT)
-        _emu = _lib.bind(C.CDLL(EMU_SO))
+        _emu = _lib.bind(C.CDLL(EMU_SO), debug=True)
         assert _emu.dr_backend() == b'hipemu'
     return _emu
 

@@ -107,7 +107,7 @@ def _run(be, B, H, W, Cin, Cout, k, relu=True, with_res=False, consumer=None, se
                        be.ptr(o['y']), be.ptr(o['raw']), be.ptr(bnc), be.ptr(ov['mm_next']), be.ptr(ov['mv_next']),
                        be.ptr(o['dout_used']), be.ptr(o['draw']), be.ptr(ov['dgamma']), be.ptr(ov['dbeta']),
                        be.ptr(o['dres']) if with_res else None, 0, 0)
-    rc = be.lib.dr_dbg_bn_layer(C.byref(a), be.stream)
+    rc = be.dbg.dr_dbg_bn_layer(C.byref(a), be.stream)
     assert rc == 0, rc
     be.sync()
     if return_raw_draw:                       # the draw / y buffers as the kernels left them (bf16-storage check of the training tests)
@@ -199,7 +199,7 @@ def test_bias_conv_backward_from_the_readers_dgrad(be):
         pad = lambda a, stride: np.concatenate([a, np.full(a.shape[:-1] + (stride - a.shape[-1],), np.nan, np.float32)], -1)
         d_out, d_gr, d_wr = be.dev(pad(out, cs)), be.dev(pad(gr, gr_cs)), be.dev(wr)
         d_g, d_b = be.dev(np.full((B * H * W, cs), -777.0, np.float32)), be.dev(np.full(Cc, 0.5, np.float32))
-        rc = be.lib.dr_dbg_act_dgrad(B, H, W, Cc, Cr, kr, be.ptr(d_out), be.ptr(d_gr), gr_cs, be.ptr(d_wr), factor, be.ptr(d_g),
+        rc = be.dbg.dr_dbg_act_dgrad(B, H, W, Cc, Cr, kr, be.ptr(d_out), be.ptr(d_gr), gr_cs, be.ptr(d_wr), factor, be.ptr(d_g),
                                      be.ptr(d_b), be.stream)
         assert rc == 0, rc
         be.sync()

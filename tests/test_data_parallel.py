@@ -46,7 +46,7 @@ class _EmuEngine:
 
     def forward_train(self, dm, mode, keep_mask, seed):
         import ctypes as C
-        self.h.call('dr_forward_train', dm.shape[0], dm.ctypes.data, 0, None, C.c_uint64(seed), None)
+        self.h.call('dr_forward_train', dm.shape[0], dm.ctypes.data, int(mode), None, C.c_uint64(seed), None)
 
     def loss(self, dm, pose, cfg, com):
         out = np.zeros(4, np.float32)
@@ -95,6 +95,28 @@ def _worker(rank, world, init_file, out_dir):
     dist.destroy_process_group()
 
 
+def _dropout_worker(rank, world, init_file, out_dir):
+    """Both ranks get the SAME crops and parameters and run with DR_DROPOUT_RNG: whatever differs between them is the mask."""
+    sys.path.insert(0, ROOT)
+    dist.init_process_group('gloo', init_method='file://' + init_file, rank=rank, world_size=world)
+    from densereg_amd.parallel import DataParallelTrainer
+    from oracle.graph import conv_specs
+    eng = _EmuEngine()
+    eng.load_params(_params())
+    tr = DataParallelTrainer(eng, dataset='nyu', sub_batch=2, dist=dist)
+    ndm, poses, cfgs, coms = _data(0)
+    name = [c.name for c in conv_specs(eng.cfg) if c.cout == 512 and not c.bn][0]          # um_full 1: bias + ReLU + dropout
+    acts = []
+    for i in range(2):                      # 2 micro-steps = 1 optimizer step
+        tr.micro_step(ndm, poses, cfgs, coms, seed=i, dropout_mode=2)
+        if i == 0:
+            acts.append(eng.be.read_activation(eng.h, name, (B, 32, 32, 512)))
+    assert tr.global_step == 1
+    got = eng.h.read_params()
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), act=acts[0], **{k.replace('/', '|'): v for k, v in got.items()})
+    dist.destroy_process_group()
+
+
 @pytest.mark.timeout(900)
 def test_two_rank_gloo_step_matches_single_process_reference():
     world = 2
@@ -128,9 +150,40 @@ def test_two_rank_gloo_step_matches_single_process_reference():
         total = g if total is None else total + g
     eng.flat_view('grad').copy_(total)
     from densereg_amd.parallel import GRAD_CLIP, learning_rate
-    eng.apply_adam(learning_rate(0, 'nyu', B, SUB), float(SUB * world), 1, GRAD_CLIP)
+    eng.apply_adam(learning_rate(0, 'nyu', B * world, SUB), float(SUB * world), 1, GRAD_CLIP)      # the GLOBAL batch, as the trainer
     ref = eng.h.read_params()
     for k in names:
         np.testing.assert_allclose(r0[k], ref[k.replace('|', '/')], rtol=1e-6, atol=1e-7, err_msg=k)
     changed = sum(float(np.abs(r0[k] - params[k.replace('|', '/')]).max()) > 0 for k in names)
     assert changed > len(names) * 0.9
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_dropout_masks_differ_and_replicas_stay_in_lock_step():
+    """SURVEY 8(e) / train_multi_gpu.py:63-90: each tower draws its own dropout masks.  Two ranks fed IDENTICAL crops and
+    parameters with DR_DROPOUT_RNG: the kept units of um_full1 must differ between the ranks (the seed carries the rank,
+    parallel.rank_seed), about half are dropped on each, and after the all-reduced optimizer step both replicas hold
+    identical parameters."""
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, 'rdzv')
+        mp.spawn(_dropout_worker, args=(world, init_file, d), nprocs=world, join=True)
+        r0 = dict(np.load(os.path.join(d, 'rank0.npz')))
+        r1 = dict(np.load(os.path.join(d, 'rank1.npz')))
+    a0, a1 = r0.pop('act'), r1.pop('act')
+    live = (a0 != 0) | (a1 != 0)                       # units with a positive pre-activation that at least one rank kept
+    assert live.sum() > 1000
+    both = ((a0 != 0) & (a1 != 0)).sum() / live.sum()  # independent fair masks: P(both | at least one) = 1/3
+    assert 0.25 < both < 0.42, both
+    k = (a0 != 0) & (a1 != 0)
+    np.testing.assert_array_equal(a0[k], a1[k])        # same inputs and weights: a unit both ranks kept has the same value
+    from oracle.graph import NetConfig, trainable_names
+    for n in (n.replace('/', '|') for n in trainable_names(NetConfig(*CFG))):
+        np.testing.assert_array_equal(r0[n], r1[n], err_msg=n)
+
+
+def test_rank_seed_is_injective_over_ranks_and_micro_steps():
+    from densereg_amd.parallel import rank_seed
+    seen = {rank_seed(m, r, 8) for m in range(50) for r in range(8)}
+    assert len(seen) == 400
+    assert rank_seed(7, 0, 1) == 7                      # one rank: the micro-step counter itself, as before

@@ -74,10 +74,10 @@ def test_conv_splitk_kernel_fused_epilogue(be, case, tile):
     res = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
     mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if k == 1 else None
     try:
-        assert be.lib.dr_dbg_force_tile(tile) == 0
+        assert be.dbg.dr_dbg_force_tile(tile) == 0
         y, st = be.conv2d(x, w, scale, shift, True, res, mask, -0.5, want_stats=True)
     finally:
-        be.lib.dr_dbg_force_tile(-1)
+        be.dbg.dr_dbg_force_tile(-1)
     yr, raw = ref_conv2d(x, w, scale, shift, True, res, mask, -0.5)
     assert _rel(y, yr) < 2e-5
     np.testing.assert_allclose(st[0], raw.sum((0, 1, 2)), rtol=1e-4, atol=1e-4)
@@ -114,10 +114,10 @@ def test_conv_every_tile_shape(be, tile):
     w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
     shift = rng.standard_normal(Cout).astype(np.float32)
     try:
-        assert be.lib.dr_dbg_force_tile(tile) == 0
+        assert be.dbg.dr_dbg_force_tile(tile) == 0
         y = be.conv2d(x, w, None, shift, True)
     finally:
-        be.lib.dr_dbg_force_tile(-1)
+        be.dbg.dr_dbg_force_tile(-1)
     yr, _ = ref_conv2d(x, w, None, shift, True)
     assert _rel(y, yr) < 2e-5
     # one and two K-tiles (1x1, Cin = 12 and 20): the unrolled-by-two loop with an odd tail; 70 / 130 channels:
@@ -126,10 +126,10 @@ def test_conv_every_tile_shape(be, tile):
         x1 = rng.standard_normal((2, 4, 5, cin)).astype(np.float32)
         w1 = rng.standard_normal((1, 1, cin, Cout)).astype(np.float32)
         try:
-            be.lib.dr_dbg_force_tile(tile)
+            be.dbg.dr_dbg_force_tile(tile)
             y1 = be.conv2d(x1, w1)
         finally:
-            be.lib.dr_dbg_force_tile(-1)
+            be.dbg.dr_dbg_force_tile(-1)
         assert _rel(y1, ref_conv2d(x1, w1)[0]) < 2e-5
 
 
@@ -146,10 +146,10 @@ def test_conv_workgroup_order_with_several_column_blocks(be, tile):
         w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
         shift = rng.standard_normal(Cout).astype(np.float32)
         try:
-            assert be.lib.dr_dbg_force_tile(tile) == 0
+            assert be.dbg.dr_dbg_force_tile(tile) == 0
             y = be.conv2d(x, w, None, shift, True)
         finally:
-            be.lib.dr_dbg_force_tile(-1)
+            be.dbg.dr_dbg_force_tile(-1)
         assert _rel(y, ref_conv2d(x, w, None, shift, True)[0]) < 2e-5
 
 
@@ -176,10 +176,10 @@ def test_conv_seeded_shape_sweep(be):
         res = rng.standard_normal((B, H, W, Cout)).astype(np.float32) if rng.random() < 0.4 else None
         mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if (k == 1 and rng.random() < 0.3) else None
         try:
-            assert be.lib.dr_dbg_force_tile(tile) == 0
+            assert be.dbg.dr_dbg_force_tile(tile) == 0
             y, st = be.conv2d(x, w, scale, shift, relu, res, mask, -0.2, want_stats=True)
         finally:
-            be.lib.dr_dbg_force_tile(-1)
+            be.dbg.dr_dbg_force_tile(-1)
         yr, raw = ref_conv2d(x, w, scale, shift, relu, res, mask, -0.2)
         tag = (case, B, H, W, Cin, Cout, k, tile)
         assert _rel(y, yr) < 2e-5, tag
@@ -213,7 +213,7 @@ def test_conv_bf16_matrix_core_variant(be, tile):
     np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32, 6: 96, 7: 96, 8: 160}[tile]
     Cout = np_needed - 3
     try:
-        assert be.lib.dr_dbg_force_tile(tile) == 0 and be.lib.dr_dbg_force_bf16(1) == 0
+        assert be.dbg.dr_dbg_force_tile(tile) == 0 and be.dbg.dr_dbg_force_bf16(1) == 0
         for (cin, k, hw, extras) in ((37, 3, (9, 15), True), (67, 1, (4, 5), True), (35, 3, (5, 4), False), (64, 3, (8, 8), True),
                                      (12, 1, (3, 7), False), (96, 1, (6, 6), False), (6, 3, (4, 4), False)):
             x = rng.standard_normal((2,) + hw + (cin,)).astype(np.float32)
@@ -232,8 +232,8 @@ def test_conv_bf16_matrix_core_variant(be, tile):
             y32, _ = ref_conv2d(x, w, scale, shift, extras, res, mask, -0.5)
             assert 1e-4 < _rel(y, y32) < 3e-2, (cin, k, _rel(y, y32))
     finally:
-        be.lib.dr_dbg_force_tile(-1)
-        be.lib.dr_dbg_force_bf16(0)
+        be.dbg.dr_dbg_force_tile(-1)
+        be.dbg.dr_dbg_force_bf16(0)
 
 
 def test_bf16_operand_rounding_is_nearest_even(be):
@@ -252,9 +252,9 @@ def test_bf16_operand_rounding_is_nearest_even(be):
     expect_even = ((bits + np.uint32(0x7FFF) + ((bits >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
     np.testing.assert_array_equal(bf16_round(ties), expect_even)                         # the reference rounding itself
     try:
-        assert be.lib.dr_dbg_force_bf16(1) == 0
+        assert be.dbg.dr_dbg_force_bf16(1) == 0
         for tile in (1, 3, 6):
-            assert be.lib.dr_dbg_force_tile(tile) == 0
+            assert be.dbg.dr_dbg_force_tile(tile) == 0
             y = be.conv2d(x, eye)
             np.testing.assert_array_equal(y.reshape(4, C_), bf16_round(x).reshape(4, C_))
             # weights: diag(ties) against ones -> the rounded diagonal
@@ -262,8 +262,8 @@ def test_bf16_operand_rounding_is_nearest_even(be):
             yw = be.conv2d(np.ones((1, 1, 1, C_), np.float32), w)
             np.testing.assert_array_equal(yw.reshape(C_), expect_even)
     finally:
-        be.lib.dr_dbg_force_tile(-1)
-        be.lib.dr_dbg_force_bf16(0)
+        be.dbg.dr_dbg_force_tile(-1)
+        be.dbg.dr_dbg_force_bf16(0)
 
 
 def test_conv_plain_linear(be):

@@ -41,7 +41,7 @@ def test_maxpool_forward_and_gather_backward(be, k):
             seed = rng.standard_normal(x.shape).astype(np.float32)
             d_x, d_dy = be.dev(x), be.dev(dy)
             d_y, d_dx = be.dev(np.full((B, Ho, Wo, C), -777.0, np.float32)), be.dev(seed)
-            rc = be.lib.dr_dbg_maxpool(B, H, W, C, k, be.ptr(d_x), be.ptr(d_y), be.ptr(d_dy), be.ptr(d_dx), acc, be.stream)
+            rc = be.dbg.dr_dbg_maxpool(B, H, W, C, k, be.ptr(d_x), be.ptr(d_y), be.ptr(d_dy), be.ptr(d_dx), acc, be.stream)
             assert rc == 0, rc
             be.sync()
             np.testing.assert_array_equal(be.host(d_y).reshape(y_ref.shape), y_ref.astype(np.float32))
@@ -52,6 +52,6 @@ def test_maxpool_forward_and_gather_backward(be, k):
 
 def test_maxpool_rejects_bad_arguments(be):
     d = be.dev(np.zeros(64, np.float32))
-    assert be.lib.dr_dbg_maxpool(1, 4, 4, 6, 2, be.ptr(d), be.ptr(d), be.ptr(d), be.ptr(d), 0, be.stream) != 0      # C % 4
-    assert be.lib.dr_dbg_maxpool(1, 4, 4, 4, 5, be.ptr(d), be.ptr(d), be.ptr(d), be.ptr(d), 0, be.stream) != 0      # k
-    assert be.lib.dr_dbg_maxpool(1, 4, 4, 4, 2, None, be.ptr(d), be.ptr(d), be.ptr(d), 0, be.stream) != 0
+    assert be.dbg.dr_dbg_maxpool(1, 4, 4, 6, 2, be.ptr(d), be.ptr(d), be.ptr(d), be.ptr(d), 0, be.stream) != 0      # C % 4
+    assert be.dbg.dr_dbg_maxpool(1, 4, 4, 4, 5, be.ptr(d), be.ptr(d), be.ptr(d), be.ptr(d), 0, be.stream) != 0      # k
+    assert be.dbg.dr_dbg_maxpool(1, 4, 4, 4, 2, None, be.ptr(d), be.ptr(d), be.ptr(d), 0, be.stream) != 0

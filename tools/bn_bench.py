@@ -12,7 +12,7 @@ from densereg_amd import _lib  # noqa: E402
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load_debug()
     print('| M | C | reduce grid | apply us | GB/s | bwd reduce us | GB/s | bwd apply us | GB/s |')
     print('|---:|---:|---:|---:|---:|---:|---:|---:|---:|')
     for M, Cc in ((40960, 256), (40960, 512), (40960, 128), (40960, 64), (10240, 256), (2560, 256), (640, 256), (160, 256)):

@@ -15,7 +15,7 @@ ABL = {0: '', 1: 'no-refill', 2: 'no-mfma', 3: 'no-store', 5: '+residual', 6: 'z
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load_debug()
     B = 40
     shapes = [(32, 256, 256, 3), (32, 128, 128, 3), (32, 512, 512, 1), (32, 515, 512, 1), (32, 512, 256, 1),
               (32, 256, 512, 1), (32, 256, 128, 1), (32, 128, 256, 1), (32, 128, 64, 1), (32, 64, 128, 1),

@@ -14,7 +14,7 @@ TILES = {-1: 'auto', 0: '128x128', 1: '64x128', 2: '128x64', 3: '64x64', 4: '128
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load_debug()
     B = 40
     shapes = [(32, 256, 256, 3), (32, 128, 128, 3), (32, 512, 512, 1), (32, 515, 512, 1), (32, 512, 256, 1), (32, 256, 512, 1),
               (32, 256, 128, 1), (32, 128, 64, 1), (32, 64, 64, 3), (32, 80, 80, 3), (16, 64, 64, 3), (8, 64, 64, 3), (64, 16, 16, 3)]

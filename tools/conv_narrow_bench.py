@@ -12,7 +12,7 @@ from densereg_amd import _lib  # noqa: E402
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load_debug()
     # (B, HxW, Cin, Cout, k): S=2 F=128 at B=40 and B=8, config 5 (S=4 F=256, 64x64 maps) at B=40
     shapes = [(40, 32, 78, 78, 3), (40, 32, 65, 65, 3), (40, 32, 156, 78, 1), (40, 32, 131, 65, 1), (40, 32, 256, 156, 1), (40, 32, 78, 156, 1),
               (40, 32, 85, 85, 3), (8, 32, 78, 78, 3), (8, 32, 156, 78, 1), (4, 32, 78, 78, 3),

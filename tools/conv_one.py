@@ -14,5 +14,5 @@ hw, cin, cout, k = (int(v) for v in sys.argv[1:5])
 tile = int(sys.argv[5]) if len(sys.argv) > 5 else -1
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 ms = C.c_float()
-rc = _lib.load().dr_dbg_conv_bench(40, hw, hw, cin, cout, k, tile, 0, iters, C.byref(ms))
+rc = _lib.load_debug().dr_dbg_conv_bench(40, hw, hw, cin, cout, k, tile, 0, iters, C.byref(ms))
 print('rc', rc, 'us', ms.value * 1e3)

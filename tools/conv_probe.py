@@ -14,7 +14,7 @@ from densereg_amd import _lib  # noqa: E402
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load_debug()
     B = int(os.environ.get('PROBE_B', '40'))
     print('| HxW | Cin | Cout | k | tile | abl | us | TFLOP/s |')
     print('|---:|---:|---:|---:|---:|---:|---:|---:|')

@@ -15,7 +15,7 @@ TILES = {-1: 'auto', 3: '64x64', 5: '64x64 BK64', 6: 'split-K 32x32', 4: '128x32
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load_debug()
     B = 40
     shapes = [(hw, cin, cout, k) for hw in (16, 8, 4, 2) for (cin, cout, k) in ((64, 64, 3), (128, 64, 1), (64, 128, 1), (128, 128, 1))]
     shapes += [(32, 64, 64, 3), (32, 128, 64, 1), (32, 64, 128, 1), (64, 16, 16, 3), (64, 32, 16, 1)]

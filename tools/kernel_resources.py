@@ -13,9 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def collect():
-    """[(demangled kernel name, {'vgpr', 'agpr', 'sgpr', 'scratch', 'lds', 'occ'})] of the product build (rebuilds the library)."""
-    env = dict(os.environ, DR_HIPCC_EXTRA='-Rpass-analysis=kernel-resource-usage')
-    log = subprocess.run([os.path.join(ROOT, 'build.sh')], cwd=ROOT, env=env, capture_output=True, text=True)
+    """[(demangled kernel name, {'vgpr', 'agpr', 'sgpr', 'scratch', 'lds', 'occ'})] of the product build.  Compiles the product's
+    sources with the resource remarks INTO A TEMPORARY DIRECTORY: the shipped densereg_amd/lib/*.so is never touched."""
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix='dr_kres_') as tmp:
+        env = dict(os.environ, DR_HIPCC_EXTRA='-Rpass-analysis=kernel-resource-usage', DR_OUT_DIR=tmp)
+        log = subprocess.run([os.path.join(ROOT, 'build.sh'), '--product-only'], cwd=ROOT, env=env, capture_output=True, text=True)
     text = log.stdout + log.stderr
     rows, cur = [], None
     pats = (('sgpr', r'TotalSGPRs: (\d+)'), ('vgpr', r'\bVGPRs: (\d+)'), ('agpr', r'AGPRs: (\d+)'),

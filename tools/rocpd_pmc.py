@@ -46,16 +46,21 @@ def short_name(n):
     return None
 
 
-def to_json(fetch_db, write_db, mode, out_path):
+def to_json(fetch_db, write_db, mode, out_path, stamp_path=None):
+    """Aggregate by kernel family into out_path[mode].  stamp_path: JSON written on the GPU box when the passes ran
+    ({"kernel_source_hash", "git_head", "date"}; tools/gpu/pmc_passes.sh) -- stored as out_path[mode]["_stamp"] together with the
+    full kernel template names of each family, so that bench.py can refuse a measurement of other kernels."""
     import json
     import os
     f = per_kernel(fetch_db, 'FETCH_SIZE')
     w = per_kernel(write_db, 'WRITE_SIZE')
     agg = {}
+    names = {}
     for n in set(f) | set(w):
         k = short_name(n)
         if not k:
             continue
+        names.setdefault(k, []).append(n.split('(')[0])
         a = agg.setdefault(k, [0, 0.0, 0, 0.0])
         nf, kb_f, _ = f.get(n, (0, 0.0, 0))
         nw, kb_w, _ = w.get(n, (0, 0.0, 0))
@@ -65,11 +70,14 @@ def to_json(fetch_db, write_db, mode, out_path):
                       'launches_sampled': v[0],
                       'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950), KB -> bytes'}
                   for k, v in agg.items()}
+    stamp = json.load(open(stamp_path)) if stamp_path and os.path.exists(stamp_path) else {}
+    stamp['kernels'] = {k: sorted(set(v)) for k, v in names.items()}
+    data[mode]['_stamp'] = stamp
     json.dump(data, open(out_path, 'w'), indent=1, sort_keys=True)
 
 
 if __name__ == '__main__':
     if len(sys.argv) >= 6 and sys.argv[3] == '--json':
-        to_json(sys.argv[1], sys.argv[2], sys.argv[4], sys.argv[5])
+        to_json(sys.argv[1], sys.argv[2], sys.argv[4], sys.argv[5], sys.argv[6] if len(sys.argv) > 6 else None)
     else:
         main(sys.argv[1], sys.argv[2])

@@ -22,10 +22,10 @@ else
     # half-written .so where the loader (or the GPU box snapshot) would pick it up
     pids=()
     if [[ "${1:-}" != "--product-only" ]]; then
-        ( $HIPCC -DDR_DEBUG_HOOKS -x hip $SRC/densereg.cpp -o $OUT/libdensereg_hip_dbg.so.tmp && mv -f $OUT/libdensereg_hip_dbg.so.tmp $OUT/libdensereg_hip_dbg.so ) &
+        ( $HIPCC ${DR_HIPCC_EXTRA:-} -DDR_DEBUG_HOOKS -x hip $SRC/densereg.cpp -o $OUT/libdensereg_hip_dbg.so.tmp && mv -f $OUT/libdensereg_hip_dbg.so.tmp $OUT/libdensereg_hip_dbg.so ) &
         pids+=($!)
     fi
-    $HIPCC -x hip $SRC/densereg.cpp -o $OUT/libdensereg_hip.so.tmp ${DR_HIPCC_EXTRA:-}
+    $HIPCC ${DR_HIPCC_EXTRA:-} -x hip $SRC/densereg.cpp -o $OUT/libdensereg_hip.so.tmp
     mv -f $OUT/libdensereg_hip.so.tmp $OUT/libdensereg_hip.so
     for p in "${pids[@]}"; do wait "$p"; done
     echo "built $OUT/libdensereg_hip.so$([[ "${1:-}" != "--product-only" ]] && echo " and $OUT/libdensereg_hip_dbg.so")"

@@ -9,8 +9,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libdensereg_hip.so')
-DEBUG_LIB_PATH = os.path.join(_HERE, 'lib', 'libdensereg_hip_dbg.so')      # product sources + dr_dbg_* hooks (tests/, tools/)
+# DR_LIB_VARIANT=<name> (measurement only): load lib/variants/<name>/ instead -- the same sources built with other -D switches
+# (tools/build_variants.sh), so that compile-time experiments can be A/B-ed in one GPU visit.  Unset = the product.
+_LIBDIR = os.path.join(_HERE, 'lib', 'variants', os.environ['DR_LIB_VARIANT']) if os.environ.get('DR_LIB_VARIANT') else os.path.join(_HERE, 'lib')
+LIB_PATH = os.path.join(_LIBDIR, 'libdensereg_hip.so')
+DEBUG_LIB_PATH = os.path.join(_LIBDIR, 'libdensereg_hip_dbg.so')      # product sources + dr_dbg_* hooks (tests/, tools/)
 
 DR_OK = 0
 DROPOUT_OFF, DROPOUT_MASK, DROPOUT_RNG = 0, 1, 2

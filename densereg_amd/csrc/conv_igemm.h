@@ -66,7 +66,6 @@ struct ConvParams {
                                            // implicit arguments, whose loads sat serialised behind branches in every workgroup's prologue
     int nfast;                             // workgroup -> tile mapping: the N blocks of a row block are consecutive in dispatch order
     int bf16;                              // w holds bf16 [Kp/32][tap][Np][32] (Kp % 32 == 0): launch the BF kernels
-    int prio;                              // > 0: static per-workgroup wave priority (dr_set_wave_priority; launcher: DR_CONV_PRIO)
     int x_bf16;                            // BF kernels only: x holds bf16 elements (x_cs / x_coff in elements, channel groups of 4
                                            // zero-padded): a 16-byte slot is loaded as it is, no conversion while staging
 };
@@ -155,14 +154,7 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
 #define DR_AS(stage) ((stage) ? As1 : As0)
 #define DR_BS(stage) ((stage) ? Bs1 : Bs0)
 
-    DR_PIN_ARGS(p.x, p.x_cs, p.x_coff, p.Cin, p.B, p.H, p.W, p.ksize, p.w, p.Kp, p.Np, p.rowmask, p.zeros, p.nfast, p.gx, p.gy, p.Ng, p.prio);
-    if (p.prio) {
-        // which priority a workgroup gets only has to DIFFER between the workgroups that share a CU: (1) a hash of the linear
-        // workgroup id, (2) its 256-workgroup dispatch wave (breadth-first placement: one per CU), (3) two levels of the hash
-        const unsigned L = (unsigned)(blockIdx.y * p.gx + blockIdx.x);
-        const unsigned hsh = (L * 2654435761u) >> 13;
-        dr_set_wave_priority(p.prio == 1 ? hsh : p.prio == 2 ? (L >> 8) : p.prio == 3 ? (hsh & 1u) : p.prio == 4 ? (L >> 3) : 3u);
-    }
+    DR_PIN_ARGS(p.x, p.x_cs, p.x_coff, p.Cin, p.B, p.H, p.W, p.ksize, p.w, p.Kp, p.Np, p.rowmask, p.zeros, p.nfast, p.gx, p.gy, p.Ng);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;

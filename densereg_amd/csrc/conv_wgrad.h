@@ -26,7 +26,6 @@ struct WgradParams {
     int x_bf16;                                  // conv_wgrad_tr_kernel only: x holds bf16 elements (BnTrainParams::out_bf16)
     int g_bf16;                                  // conv_wgrad_bf16_kernel only: g holds bf16 elements (stride g_cs elements, channel
                                                  // groups of four zero-padded) -- see BnBwdParams::draw_bf16
-    int prio;                                    // > 0: static per-workgroup wave priority (dr_platform.h: dr_set_wave_priority)
 };
 
 // Tile T x T channels, 4 waves as 2 x 2, wave tile T/2 x T/2.
@@ -48,10 +47,6 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
     __shared__ __attribute__((aligned(16))) float Xs[2][BK][ST];
     __shared__ __attribute__((aligned(16))) float Gs[2][BK][ST];
 
-    if (p.prio) {
-        const unsigned hsh = ((unsigned)blockIdx.x * 2654435761u) >> 13;
-        dr_set_wave_priority(p.prio == 1 ? hsh : p.prio == 2 ? ((unsigned)blockIdx.x >> 8) : (hsh & 1u));
-    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lk = lane >> 5, li = lane & 31;

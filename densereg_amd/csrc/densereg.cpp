@@ -55,11 +55,8 @@ template <int BM, int BN, int WM, int WN, int BK = 16, int GL = 0, int BF = 0, i
 static void launch_cfg(const ConvParams& p_in, hipStream_t s) {
     // N blocks of a row block back to back in dispatch order (conv_igemm.h nfast); DR_CONV_NFAST=0: plain 2-D grid order
     static const int nfast = [] { const char* e = getenv("DR_CONV_NFAST"); return (e && e[0] == '0') ? 0 : 1; }();
-    // static per-workgroup wave priorities (conv_igemm.h, ConvParams::prio): DR_CONV_PRIO = 0 off, 1..4 the assignment
-    static const int prio = [] { const char* e = getenv("DR_CONV_PRIO"); return e ? atoi(e) : 0; }();
     ConvParams p = p_in;
     p.nfast = nfast;
-    p.prio = prio;
     const int M = p.B * p.H * p.W;
     dim3 grid(dr_ceil_div(M, BM), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, BN));
     p.gx = (int)grid.x; p.gy = (int)grid.y;

@@ -163,23 +163,6 @@ __device__ __forceinline__ float dr_load_agent_f32(const float* p) { return __hi
 __device__ __forceinline__ void dr_spin_pause() { __builtin_amdgcn_s_sleep(2); }
 #endif
 
-// Static wave priority by workgroup (conv kernels): co-resident workgroups of one launch start together, share each SIMD's
-// matrix pipe round-robin and therefore reach their store-heavy epilogues together -- the pipe idles while all of them drain.
-// Giving the workgroups of a CU DIFFERENT priorities lets the arbiter favour one (it finishes early, its epilogue and its
-// successor's prologue run under the others' MFMAs): the rounds of a launch stop being lock-stepped.  s_setprio takes an immediate.
-#if defined(DR_EMU)
-static inline void dr_set_wave_priority(unsigned) {}
-#else
-__device__ __forceinline__ void dr_set_wave_priority(unsigned pr) {
-    switch (pr & 3u) {                                   // wave-uniform: scalar branches around one s_setprio
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        case 3: __builtin_amdgcn_s_setprio(3); break;
-        default: break;
-    }
-}
-#endif
-
 // two 16-bit halves of two words in one instruction: {lo16(a), lo16(b)} (odd = 0) or {hi16(a), hi16(b)} (odd = 1), a in the
 // low half of the result (v_perm_b32)
 #if defined(DR_EMU)

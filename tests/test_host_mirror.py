@@ -82,6 +82,10 @@ def test_global_batch_is_split_over_ranks_like_the_reference_towers():
         @staticmethod
         def get_world_size():
             return 8
+
+        @staticmethod
+        def get_rank():
+            return 3
     calls = []
 
     class _Eng:
@@ -89,6 +93,7 @@ def test_global_batch_is_split_over_ranks_like_the_reference_towers():
         def zero_grad(self): pass
         def apply_adam(self, lr, div, step, clip): calls.append((lr, div, step))
     tr = DataParallelTrainer(_Eng(), dataset='msra', sub_batch=5, dist=_Dist(), all_reduce=lambda g: None)
+    assert (tr.world, tr.rank) == (8, 3)
     tr.global_step = int(decay_steps('msra', 320, 5)) + 1           # just past the first decay of the GLOBAL schedule
     tr.optimizer_step(40)
     assert math.isclose(calls[0][0], 1e-4) and calls[0][1] == 40.0 and calls[0][2] == tr.global_step

@@ -340,6 +340,7 @@ def main():
                         if mode == 'train' else 'forward(eval) + vote -> xyz mm') +
                        (', bf16 matrix cores on fp32 tensors (fp32 accumulate, epilogues, vote)' if bf16 else ''),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                       'micro_steps_in_flight': getattr(eng, 'pipeline', 1) if mode == 'train' else None,
                        'world_size': dist.get_world_size() if dist is not None else 1, 'rccl_version': rccl,
                        'conv_gflop_per_crop_fwd': eng.conv_flops_per_crop() / 1e9},
             'roofline': roof, 'cpu_baseline': cpu, 'forward_vote': fwd_vote,

@@ -72,6 +72,8 @@ SIGNATURES = {
     'dr_loss': (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _vp]),
     'dr_backward': (_i, [_vp, _i, _vp]),
     'dr_zero_grad': (_i, [_vp, _vp]),
+    'dr_set_pipeline': (_i, [_vp, _i]),
+    'dr_sync_grads': (_i, [_vp, _vp]),
     'dr_flat_grad': (_i, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
     'dr_flat_param': (_i, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
     'dr_apply_adam': (_i, [_vp, C.c_float, C.c_float, C.c_float, C.c_int64, _vp]),

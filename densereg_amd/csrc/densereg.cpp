@@ -508,7 +508,12 @@ void add_param(dr_handle* h, const std::string& name, std::initializer_list<int>
 
 }  // namespace
 
+#include "pipeline.inc"
+
 static void free_all(dr_handle* h) {
+    pipeline_drain(h);
+    if (h->slot[0].act_arena) bind_slot(h, 0);             // the working fields name slot 0's buffers again: freed below
+    free_slot1(h);
     for (void* p : {(void*)h->flat_param, (void*)h->flat_grad, (void*)h->adam_m, (void*)h->adam_v, (void*)h->flat_state, (void*)h->flat_state_next,
                     (void*)h->shadow, (void*)h->wp, (void*)h->wpT, (void*)h->fold, (void*)h->bnc,
                     (void*)h->act_arena, (void*)h->grad_arena, (void*)h->scratch, (void*)h->tiny, (void*)h->tiny_ext, (void*)h->zeros,
@@ -687,6 +692,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
     size_t off = 0;
     for (auto& t : h->tensors) {
         if (t.get() == h->input) continue;
+        t->off = off;
         t->p = h->act_arena + off;
         if (cfg->training) t->g = h->grad_arena + off;
         off += MB * t->H * t->W * t->cs;
@@ -697,6 +703,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
             auto t = std::make_unique<Tensor>();
             t->id = (int)h->tensors.size();
             t->H = c.H; t->W = c.W; t->C = c.cout; t->cs = dr_round_up(c.cout, 4); t->tag = "raw";
+            t->off = off;
             t->p = h->act_arena + off;
             off += MB * t->H * t->W * t->cs;
             c.raw = t.get();
@@ -716,6 +723,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         rt::memset_async(h->grad_arena, 0, nact * sizeof(float), nullptr);
     }
     rt::sync_stream(nullptr);
+    slot_capture0(h);
     *out = h;
     return DR_OK;
 }
@@ -778,6 +786,7 @@ static float* param_dev_ptr(dr_handle* h, const ParamInfo& p) {
 
 int dr_load_param(dr_handle* h, const char* name, const float* host, size_t count) {
     if (!h || !name || !host) return DR_E_INVALID;
+    pipeline_drain(h);
     const ParamInfo* p = find_param(h, name);
     if (!p) {
         int slot = 0;
@@ -816,6 +825,7 @@ int dr_load_param(dr_handle* h, const char* name, const float* host, size_t coun
 
 int dr_read_param(dr_handle* h, const char* name, float* host, size_t count) {
     if (!h || !name || !host) return DR_E_INVALID;
+    pipeline_drain(h);
     const ParamInfo* p = find_param(h, name);
     if (!p) {
         int slot = 0;
@@ -901,6 +911,7 @@ int dr_set_precision(dr_handle* h, int precision) {
     if (!h) return DR_E_INVALID;
     if (precision != DR_PREC_F32 && precision != DR_PREC_BF16) DR_FAIL(h, DR_E_INVALID, "dr_set_precision: unknown precision %d", precision);
     if (precision != h->precision) {
+        pipeline_drain(h);
         rt::sync_stream(nullptr);
         if (h->pack_dev) { rt::dfree(h->pack_dev); h->pack_dev = nullptr; }     // the packing table depends on the element type
         h->precision = precision;
@@ -914,6 +925,7 @@ int dr_set_precision(dr_handle* h, int precision) {
 int dr_finalize_params(dr_handle* h, dr_stream stream) {
     if (!h) return DR_E_INVALID;
     DR_ENTER(h);
+    pipeline_drain(h);
     hipStream_t s = (hipStream_t)stream;
     int rc = repack_weights(h, s);
     if (rc) return rc;
@@ -1098,6 +1110,7 @@ static int run_simple_op(dr_handle* h, const Op& op, int B, hipStream_t s, bool 
 
 static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s) {
     if (!h->finalized) DR_FAIL(h, DR_E_STATE, "forward before dr_finalize_params");
+    pipeline_drain(h);                                       // (training handle with two micro-step slots: the bound slot's buffers are reused)
     if (B < 1 || B > h->cfg.max_batch) DR_FAIL(h, DR_E_INVALID, "batch %d outside [1, max_batch=%d]", B, h->cfg.max_batch);
     DR_ENTER(h);
     h->dm_in = dm;
@@ -1203,6 +1216,7 @@ int dr_read_maps(dr_handle* h, int B, int stack, float* hm, float* hm3, float* u
     if (stack < 0 || stack >= h->cfg.num_stack) DR_FAIL(h, DR_E_INVALID, "dr_read_maps: stack %d", stack);
     if (B < 1 || B > h->last_B) DR_FAIL(h, DR_E_INVALID, "dr_read_maps: B=%d but the last forward ran %d", B, h->last_B);
     hipStream_t s = (hipStream_t)stream;
+    if (h->pipe_depth == 2 && h->slot[h->cur_slot].fwd_recorded) rt::stream_wait_event(s, h->slot[h->cur_slot].fwd_done);
     if (hm) copy_out(h, h->hm[stack], B, hm, s);
     if (hm3) copy_out(h, h->hm3[stack], B, hm3, s);
     if (um) copy_out(h, h->um[stack], B, um, s);
@@ -1236,6 +1250,7 @@ int dr_infer(dr_handle* h, int B, const float* dm, const float* cfg, const float
 
 int dr_read_activation(dr_handle* h, const char* scope, int B, float* host, size_t count) {
     if (!h || !scope || !host) return DR_E_INVALID;
+    pipeline_drain(h);
     for (const Op& op : h->ops) {
         if ((op.kind != OP_CONV && op.kind != OP_STEM) || h->convs[op.conv].name != scope) continue;
         const Tensor* t = op.out.t;
@@ -1284,6 +1299,7 @@ extern "C" int dr_lookback_expired(dr_handle* h) {
 
 extern "C" int dr_profile_enable(dr_handle* h, int on) {
     if (!h) return DR_E_INVALID;
+    pipeline_drain(h);
     rt::sync_stream(nullptr);
     for (auto& r : h->prof) { rt::event_destroy(r.a); rt::event_destroy(r.b); }
     h->prof.clear();

@@ -17,6 +17,7 @@ struct Tensor {
     int H = 0, W = 0, C = 0, cs = 0;   // cs = channel stride (C rounded up to 4)
     float* p = nullptr;                // forward values   [max_batch*H*W*cs]
     float* g = nullptr;                // gradient buffer (training handles)
+    size_t off = 0;                    // p = <activation arena> + off, g = <gradient arena> + off: re-bound per micro-step slot (StepSlot)
     bool needs_grad = true;
     bool needs_zero = false;           // gradient buffer must be zeroed before a backward pass (see plan_backward)
     int grad_C = 0;                    // channels [0, grad_C) of the gradient have a consumer (plan_backward): the tail of a
@@ -65,6 +66,7 @@ struct ConvLayer {
     int ep_fwd = 0, ep_bwd = 0;        // launches so far of the look-back apply kernels (targets of the hand-off counters)
     float* g_keep = nullptr;           // small layers (training): a private dRaw buffer that outlives the layer's step of the
                                        // backward sweep, so its weight gradient can run in the grouped launch at the end
+    size_t g_keep_off = (size_t)-1;    // g_keep = <slot's g_keep arena> + g_keep_off ((size_t)-1: none)
 };
 
 enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_UPADD, OP_UVD, OP_COPY, OP_FORK, OP_JOIN };
@@ -84,6 +86,7 @@ struct Op {
     int dropout = -1;                  // dropout slot index (stack*2 + i) or -1
     int pool_k = 0;
     unsigned char* pool_arg = nullptr; // training: arg-max position per pooled element, [B*Ho*Wo][C] bytes (maxpool_kernel)
+    size_t pool_off = (size_t)-1;      // pool_arg = <slot's arg-max arena> + pool_off
     int lane = 0;                      // stream lane the op runs on (FORK/JOIN: the parent lane)
     int lane2 = 0;                     // FORK/JOIN: the child lane
     int ev = -1;                       // FORK/JOIN: index into dr_handle::lane_ev
@@ -117,6 +120,28 @@ static const char* const kKernelNames[KID_COUNT] = {
 
 struct ProfRecord { rt::Event a, b; int kid; int tag; double flops; double bytes; };
 struct RegSeg;
+
+// Everything ONE training micro-step in flight owns: what its forward writes and its backward reads (activations, raw conv outputs,
+// BatchReNorm step values, arg-max bytes, the depth mask, copies of the caller's inputs), the backward sweep's scratch, and a gradient
+// accumulator.  A handle has one slot -- or two (dr_set_pipeline(h, 2)): consecutive micro-steps then alternate between the slots, each
+// on its slot's stream, and the kernels of micro-step k+1 fill the launch boundaries and small-grid chains of micro-step k (measured:
+// two independent engines on one MI355X give 2392 crops/s together against 2047 for one, profiles/r03_experiments.md).  The executors
+// keep reading the handle's working fields (act_arena, fold, tiny, ... and every Tensor::p / g): bind_slot() points them at a slot.
+struct StepSlot {
+    float* act_arena = nullptr; float* grad_arena = nullptr; float* fold = nullptr; float* bnc = nullptr; float* tiny = nullptr;
+    float* scratch = nullptr; float* g_keep_arena = nullptr; unsigned char* pool_arg_arena = nullptr;
+    double* stat_part = nullptr; double* stat_part2 = nullptr; float* bn_coef = nullptr; float* wg_partial = nullptr;
+    double* loss_acc = nullptr; float* gacc = nullptr;
+    float* dm_copy = nullptr; float* aux_copy = nullptr;     // the caller's crops / poses | camera | centres of mass of this micro-step
+    WgradGroupSeg* group_dev = nullptr; std::vector<WgradGroupSeg> group_uploaded;
+    FoldSeg* fold_dev = nullptr; std::vector<FoldSeg> fold_uploaded;       // (a slot's table may be re-planned while the other's fold is queued)
+    hipStream_t stream = nullptr;                            // library-owned (two slots), else the caller's stream is used
+    hipStream_t wg_stream = nullptr; rt::Event wg_ready{}, wg_done{};
+    rt::Event in_ev{}, fwd_done{}, loss_done{}, step_done{};
+    bool fwd_recorded = false, step_recorded = false;        // the events above carry a record
+    bool grads_dirty = false;                                // gacc holds contributions not yet folded into slot 0's (dr_sync_grads)
+    bool owns = false;                                       // slot 1: buffers allocated by dr_set_pipeline (slot 0 aliases the handle's)
+};
 
 }  // namespace dr
 
@@ -185,7 +210,6 @@ struct dr_handle {
     std::vector<dr::FoldSeg> fold_host;                     // segments of the sweep in progress
     void* zero_dev = nullptr; int zero_nseg = 0;            // ZeroSeg table of the gradient buffers dr_loss clears (plan_backward)
     dr::FoldSeg* fold_dev = nullptr;                        // device copy (capacity = number of convs)
-    std::vector<dr::FoldSeg> fold_uploaded;                 // what fold_dev currently holds (re-uploaded only on change)
     size_t fold_head = 0;                                  // floats at the start of wg_partial kept for immediate folds
     size_t fold_used = 0;                                  // floats of wg_partial handed out in this sweep
     int fold_blocks = 0;
@@ -194,7 +218,7 @@ struct dr_handle {
     // grouped weight gradient of the small layers (conv_wgrad.h: conv_wgrad_group_kernel), single-stream executor
     unsigned char* pool_arg_arena = nullptr;                // max-pool arg-max bytes (Op::pool_arg)
     float* g_keep_arena = nullptr;                          // the layers' private dRaw buffers
-    std::vector<dr::WgradGroupSeg> group_host, group_uploaded;   // segments of the sweep in progress / what group_dev holds
+    std::vector<dr::WgradGroupSeg> group_host;              // segments of the sweep in progress (what group_dev holds: StepSlot::group_uploaded)
     dr::WgradGroupSeg* group_dev = nullptr;
     int group_blocks = 0; double group_flops = 0, group_bytes = 0;
     bool group_wgrad = true;                                // DR_GROUP_WGRAD=0: every layer launches its own weight gradient
@@ -214,4 +238,10 @@ struct dr_handle {
     bool bf16_draw = true;                                  // DR_BF16_DRAW=0: dRaw stays fp32 on the bf16 matrix-core path (train_exec.inc)
     bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold
     const float* dm_train = nullptr;                       // input of the last dr_forward_train
+    // micro-step slots (StepSlot above)
+    dr::StepSlot slot[2];
+    int pipe_depth = 1;                                    // 1: every call runs on the caller's stream; 2: two micro-steps in flight
+    int cur_slot = 0, next_slot = 0;                       // slot of the micro-step in progress / of the next dr_forward_train
+    float* gacc = nullptr;                                 // gradient accumulator of the bound slot (slot 0's IS flat_grad)
+    size_t n_keep = 0, n_pool_arg = 0, n_loss_acc = 0, n_group_dev = 0;   // sizes a second slot needs (elements / bytes / doubles / segments)
 };

@@ -820,6 +820,14 @@ __global__ __launch_bounds__(256) void losses_out_kernel(const double* loss_part
 }
 
 // ------------------------------------------------------------------------------------------------
+// a[i] += b[i]; b[i] = 0 -- the second micro-step slot's accumulated gradient folded into the flat accumulator (pipeline.inc)
+__global__ __launch_bounds__(256) void grad_merge_kernel(float* a, float* b, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        a[i] += b[i];
+        b[i] = 0.f;
+    }
+}
+
 // Fused accumulate-average / clip / Adam over the flat buffers (train_single_gpu.py:86-89).
 //   g = clip(acc/div, +-clip) ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; theta -= lr_t m/(sqrt(v)+eps)
 // ------------------------------------------------------------------------------------------------

@@ -72,10 +72,17 @@ class DataParallelTrainer:
         self.global_step = 0                     # optimizer steps applied so far
         self.flat_grad = engine.flat_view('grad') if engine is not None else None
         if engine is not None:
+            # an optimizer step after EVERY micro-step leaves nothing to overlap and the second slot's bookkeeping only costs
+            # (measured: 1867 against 2054 crops/s): one micro-step at a time then
+            if self.sub_batch < 2 and getattr(engine, 'pipeline', 1) == 2:
+                engine.set_pipeline(1)
             engine.zero_grad()
 
     def reduce_gradients(self):
         if self.world > 1 or (self.dist is not None and os.environ.get('DR_FORCE_ALLREDUCE') == '1'):
+            sync = getattr(self.eng, 'sync_grads', None)
+            if sync is not None:
+                sync()                       # micro-steps in flight finish and their slots' gradients become one sum (dr_sync_grads)
             if self._all_reduce is not None:
                 self._all_reduce(self.flat_grad)
             else:

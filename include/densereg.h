@@ -142,6 +142,20 @@ int dr_loss(dr_handle* h, int B, const float* dm_norm_dev, const float* pose_mm_
  * regulariser term, into the flat gradient accumulator (train_single_gpu.py:84 accum_op). */
 int dr_backward(dr_handle* h, int B, dr_stream stream);
 int dr_zero_grad(dr_handle* h, dr_stream stream);                       /* reset_op (:83) */
+/* Micro-steps in flight (training handles; default 1).  The reference accumulates `sub_batch` micro-steps on the same weights
+ * between two optimizer steps (train_single_gpu.py:138-150); consecutive micro-steps depend on each other only through the
+ * BatchReNorm moving statistics (forward k+1 reads what forward k wrote, slim/ops.py:134-162) and the gradient sum.  With
+ * depth 2 the handle owns two sets of per-micro-step buffers and two library streams: dr_forward_train / dr_loss / dr_backward
+ * of micro-step k are enqueued on set k % 2's stream (after whatever `stream` holds at the time of the call), forward k+1
+ * starts when forward k has finished, and the two kernel streams overlap.  Inputs are copied at enqueue time; dr_loss orders
+ * `stream` behind the loss kernels (losses_dev is valid in stream order); dr_zero_grad, dr_sync_grads and dr_apply_adam order
+ * `stream` behind every micro-step in flight.  Each set accumulates its own gradient, summed in a fixed order by
+ * dr_sync_grads / dr_apply_adam: results are deterministic, and equal depth 1's up to the rounding of that one addition.
+ * Entry points that read the handle's buffers from the host (dr_read_param, dr_read_activation, ...) drain the pipeline first. */
+int dr_set_pipeline(dr_handle* h, int depth);
+/* Orders `stream` behind every micro-step in flight and folds all sets' accumulated gradients into the buffer dr_flat_grad
+ * names (call it before an all-reduce of that buffer: train_multi_gpu.py:16-39).  A no-op at depth 1. */
+int dr_sync_grads(dr_handle* h, dr_stream stream);
 /* Flat fp32 views in TF trainable-variable creation order (for RCCL all-reduce / checkpoints). */
 int dr_flat_grad(dr_handle* h, float** dev_ptr, size_t* count);
 int dr_flat_param(dr_handle* h, float** dev_ptr, size_t* count);

@@ -59,6 +59,9 @@ def parse():
     ap.add_argument('--dataset', default='', choices=['', 'icvl', 'nyu', 'msra'], help='default: nyu for train, icvl for infer')
     ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
                     help='matrix-core arithmetic of the convolutions; bf16 = BASELINE config 5\'s conv path (fp32 stays the headline)')
+    ap.add_argument('--replicas', type=int, default=2,
+                    help='forward(eval)+vote: inference replicas per GPU, consecutive batches alternate between them '
+                         '(densereg_amd/serving.py; 1 = one engine, one stream)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-forward-vote', action='store_true', help='train mode: skip the forward(eval)+vote leg')
@@ -224,9 +227,23 @@ def main():
     xyz = eng.new(B, 3 * J)
     trainer = DataParallelTrainer(eng, dataset=dataset, sub_batch=args.sub_batch, dist=dist) if mode == 'train' else None
 
+    # forward(eval)+vote throughput: `--replicas` engines with the same weights, each on its own stream, take the batches in turn
+    # (north-star: inference = replicas; the single-engine figure is reported next to it)
+    def make_pool(Jn):
+        from densereg_amd.serving import ReplicaPool
+        pool = ReplicaPool(args.replicas, S, F, Jn, HW, 3, B, local)
+        if bf16:
+            pool.set_precision('bf16')
+        pool.load_params(random_params(pool))
+        return pool, [pool.engines[0].new(B, 3 * Jn) for _ in range(args.replicas)]
+    pool, pool_out = make_pool(J) if (mode == 'infer' and args.replicas > 1) else (None, None)
+
     def step(i):
         if mode == 'infer':
-            eng.infer(d_dm, d_cfg, d_com, out=xyz)
+            if pool is not None:
+                pool.submit(d_dm, d_cfg, d_com, out=pool_out[i % args.replicas])
+            else:
+                eng.infer(d_dm, d_cfg, d_com, out=xyz)
         else:
             trainer.micro_step(d_dm, d_pose, d_cfg, d_com, seed=i)
 
@@ -253,6 +270,12 @@ def main():
         return el
 
     dt = timed(step)
+    single = None
+    if pool is not None:                                     # the same workload on ONE engine / stream
+        sdt = timed(lambda i: eng.infer(d_dm, d_cfg, d_com, out=xyz))
+        single = {'value': B * world * args.steps / sdt, 'ms_per_step': sdt / args.steps * 1e3}
+        pool.close()
+        pool = None
 
     # ---- roofline leg: separate profiled pass (events around every op), same workload ------------
     roof = None
@@ -307,11 +330,19 @@ def main():
         idm, _ip, icfg, icom, _ = make_crops(B, 'icvl', seed=20240, rank=rank, hw=HW)
         i_dm, i_cfg, i_com = ieng.norm_dm(t(idm), t(icom)), t(icfg), t(icom)
         i_xyz = ieng.new(B, 3 * Ji)
-        idt = timed(lambda i: ieng.infer(i_dm, i_cfg, i_com, out=i_xyz))
+        idt1 = timed(lambda i: ieng.infer(i_dm, i_cfg, i_com, out=i_xyz))
+        idt = idt1
+        if args.replicas > 1:
+            ipool, iout = make_pool(Ji)
+            idt = timed(lambda i: ipool.submit(i_dm, i_cfg, i_com, out=iout[i % args.replicas]))
+            ipool.close()
         fwd_vote = {'metric': 'depth-crops/sec fwd(eval)+vote, %d-stack fea=%d @%dx%d' % (S, F, HW, HW),
                     'value': B * world * args.steps / idt, 'unit': 'crops/s', 'ms_per_step': idt / args.steps * 1e3,
                     'steps': args.steps, 'warmup': args.warmup,
-                    'workload': 'ICVL S=%d F=%d J=%d B=%d/GPU %dx%d forward(eval) + vote -> xyz mm, %d replica(s)' % (S, F, Ji, B, HW, HW, world),
+                    'workload': 'ICVL S=%d F=%d J=%d B=%d/GPU %dx%d forward(eval) + vote -> xyz mm, %d GPU(s) x %d replica(s) per GPU '
+                                '(batches alternate between the replicas, each on its own stream)' % (S, F, Ji, B, HW, HW, world, args.replicas),
+                    'replicas_per_gpu': args.replicas,
+                    'single_replica': {'value': B * world * args.steps / idt1, 'ms_per_step': idt1 / args.steps * 1e3},
                     'conv_gflop_per_crop_fwd': ieng.conv_flops_per_crop() / 1e9}
         ieng.close()
 
@@ -341,6 +372,7 @@ def main():
                        (', bf16 matrix cores on fp32 tensors (fp32 accumulate, epilogues, vote)' if bf16 else ''),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
                        'micro_steps_in_flight': getattr(eng, 'pipeline', 1) if mode == 'train' else None,
+                       'replicas_per_gpu': args.replicas if mode == 'infer' else None, 'single_replica': single,
                        'world_size': dist.get_world_size() if dist is not None else 1, 'rccl_version': rccl,
                        'conv_gflop_per_crop_fwd': eng.conv_flops_per_crop() / 1e9},
             'roofline': roof, 'cpu_baseline': cpu, 'forward_vote': fwd_vote,

@@ -129,8 +129,11 @@ struct RegSeg;
 // keep reading the handle's working fields (act_arena, fold, tiny, ... and every Tensor::p / g): bind_slot() points them at a slot.
 struct StepSlot {
     float* act_arena = nullptr; float* grad_arena = nullptr; float* fold = nullptr; float* bnc = nullptr; float* tiny = nullptr;
-    float* scratch = nullptr; float* g_keep_arena = nullptr; unsigned char* pool_arg_arena = nullptr;
-    double* stat_part = nullptr; double* stat_part2 = nullptr; float* bn_coef = nullptr; float* wg_partial = nullptr;
+    float* g_keep_arena = nullptr; unsigned char* pool_arg_arena = nullptr;
+    // per executor lane (Op::lane indexes these whether or not the lanes run on their own streams): dRaw scratch, the partial-sum
+    // rows of the BatchReNorm reductions (own layer / written by a dgrad for the next layer), backward coefficients, wgrad slabs
+    float* scratch_l[DR_MAX_LANES] = {}; double* stat_part_l[DR_MAX_LANES] = {}; double* stat_part2_l[DR_MAX_LANES] = {};
+    float* bn_coef_l[DR_MAX_LANES] = {}; float* wg_partial_l[DR_MAX_LANES] = {};
     double* loss_acc = nullptr; float* gacc = nullptr;
     float* dm_copy = nullptr; float* aux_copy = nullptr;     // the caller's crops / poses | camera | centres of mass of this micro-step
     WgradGroupSeg* group_dev = nullptr; std::vector<WgradGroupSeg> group_uploaded;

@@ -88,7 +88,7 @@ def test_two_slots_reproduce_the_one_slot_trajectory(be):
     # near-zero gradient changed sign: the first Adam step moves EVERY weight by lr whatever the gradient's size), so later losses agree to
     # a few per cent on this random-weight network, not bitwise -- the exact statement is the first-window test below
     for i in range(2, len(batches)):
-        np.testing.assert_allclose(lo2[i], lo1[i], rtol=5e-2, err_msg='micro-step %d' % i)
+        np.testing.assert_allclose(lo2[i], lo1[i], rtol=2e-3, err_msg='micro-step %d' % i)       # measured on MI355X: 2e-7
     changed = 0
     for k in p1:
         if 'moving' in k or k.endswith(('r_max', 'd_max', 'curr_t')):
@@ -103,6 +103,15 @@ def test_two_slots_reproduce_the_one_slot_trajectory(be):
     for k in p2:
         np.testing.assert_array_equal(p2[k], p2b[k], err_msg=k)
     assert len(g2b) == 2 and all(g > 0 for g in g2b)
+    if be.name == 'gpu':
+        # ... run after run: a backward of one slot overlapping the forward of the other through ANY shared scratch shows up here
+        # as a different bit somewhere (it did: the per-lane reduction rows were shared until every lane's set became per slot)
+        for _ in range(3):
+            lo2c, p2c, _ = _trajectory(be, cfg, params, batches, B, 2)
+            for a, b in zip(lo2, lo2c):
+                np.testing.assert_array_equal(a, b)
+            for k in p2:
+                np.testing.assert_array_equal(p2[k], p2c[k], err_msg=k)
 
 
 def test_two_slots_first_window_matches_one_slot_gradients(be):
@@ -187,3 +196,38 @@ def test_pipeline_ragged_batches_and_depth_switch(gpu):
     h.close()
     sc = np.abs(g_ref).max()
     assert np.abs(g_switch - g_ref).max() <= 4e-6 * sc + 1e-12
+
+
+@pytest.mark.gpu
+def test_inference_replicas_equal_one_engine(gpu):
+    """densereg_amd/serving.py: k replicas (same weights, one stream each) taking batches in turn give, batch by batch, the
+    bits one engine gives -- submitted back to back without waiting, results collected afterwards."""
+    import torch
+    from densereg_amd.data.synthetic import make_crops
+    from densereg_amd.engine import Engine
+    from densereg_amd.serving import ReplicaPool
+    from oracle import net
+    from oracle.graph import NetConfig
+    S, F, J, B = 1, 32, 16, 5
+    params = net.init_params(NetConfig(S, F, J), 11)
+    eng = Engine(S, F, J, 128, 3, B, 0, training=False)
+    eng.load_params(params)
+    pool = ReplicaPool(3, S, F, J, 128, 3, B, 0)
+    pool.load_params(params)
+    dev = eng.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    want, got = [], []
+    for i in range(7):
+        dm, _p, cfgs, coms, _ = make_crops(B, 'icvl', seed=500 + i)
+        d_dm = eng.norm_dm(t(dm), t(coms))
+        want.append(eng.infer(d_dm, t(cfgs), t(coms)).clone())
+        got.append(pool.submit(d_dm, t(cfgs), t(coms)))           # inputs go out of scope right away: the pool keeps them alive
+    for (xyz, ticket), ref in zip(got, want):
+        pool.wait(ticket)
+        torch.cuda.current_stream(dev).synchronize()
+        np.testing.assert_array_equal(xyz.cpu().numpy(), ref.cpu().numpy())
+    assert np.isfinite(want[0].cpu().numpy()).all()
+    xyz = pool.infer(d_dm, t(cfgs), t(coms))                       # the synchronous form
+    np.testing.assert_array_equal(xyz.cpu().numpy(), want[-1].cpu().numpy())
+    pool.close()
+    eng.close()

@@ -59,7 +59,7 @@ def parse():
     ap.add_argument('--dataset', default='', choices=['', 'icvl', 'nyu', 'msra'], help='default: nyu for train, icvl for infer')
     ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
                     help='matrix-core arithmetic of the convolutions; bf16 = BASELINE config 5\'s conv path (fp32 stays the headline)')
-    ap.add_argument('--replicas', type=int, default=2,
+    ap.add_argument('--replicas', type=int, default=3,
                     help='forward(eval)+vote: inference replicas per GPU, consecutive batches alternate between them '
                          '(densereg_amd/serving.py; 1 = one engine, one stream)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -319,6 +319,9 @@ def main():
                                                 'gbs': (s['bytes'] / (s['total_ms'] * 1e-3) / 1e9) if s['bytes'] else None}
                                     for s in stats}}
 
+    eng_flops, eng_pipeline = eng.conv_flops_per_crop(), getattr(eng, 'pipeline', 1)
+    if mode == 'train':
+        eng.close()                                          # its streams and buffers are not needed by the next leg
     # ---- the other north-star figure, same process, same N: forward(eval) + vote on ICVL crops (replicas, no collective) ----
     fwd_vote = None
     if mode == 'train' and not args.no_forward_vote:
@@ -371,10 +374,10 @@ def main():
                         if mode == 'train' else 'forward(eval) + vote -> xyz mm') +
                        (', bf16 matrix cores on fp32 tensors (fp32 accumulate, epilogues, vote)' if bf16 else ''),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                       'micro_steps_in_flight': getattr(eng, 'pipeline', 1) if mode == 'train' else None,
+                       'micro_steps_in_flight': eng_pipeline if mode == 'train' else None,
                        'replicas_per_gpu': args.replicas if mode == 'infer' else None, 'single_replica': single,
                        'world_size': dist.get_world_size() if dist is not None else 1, 'rccl_version': rccl,
-                       'conv_gflop_per_crop_fwd': eng.conv_flops_per_crop() / 1e9},
+                       'conv_gflop_per_crop_fwd': eng_flops / 1e9},
             'roofline': roof, 'cpu_baseline': cpu, 'forward_vote': fwd_vote,
         }
         os.write(json_fd, (json.dumps(out) + '\n').encode())

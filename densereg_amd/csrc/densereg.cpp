@@ -636,6 +636,11 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         h->multi_stream = multi && multi[0] == '1' && !(single && single[0] == '1');
         const char* graphs = getenv("DR_GRAPHS");
         h->use_graphs = graphs && graphs[0] == '1';      // opt-in: measured no gain (B=1: 1.87 ms either way, GPU-bound)
+        // Created unconditionally, BEFORE the low-priority weight-gradient stream below, although only DR_GRAPHS=1 records on it:
+        // measured on this stack (ROCm 7.2, MI355X), a process whose first library stream is the low-priority one runs the
+        // training step at 870 crops/s instead of 2050 (the low-priority queue and the caller's are then scheduled one after the
+        // other instead of side by side); with a normal-priority stream created first -- or a normal-priority side stream, which
+        // measures the same 2050 -- the effect is gone (profiles/r03_experiments.md, visit 18).
         h->cap_stream = rt::stream_create();
         const char* fuse = getenv("DR_FUSE_BN_BWD");
         h->fuse_bn_bwd = !(fuse && fuse[0] == '0');
@@ -652,7 +657,8 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
             // Measured and dropped (round 2): a CU-masked side stream (hipExtStreamCreateWithCUMask, 96-224 CUs: 31-37 ms per step
             // against 20.6) and side launches cut to ~256-768 workgroups so that every CU keeps free slots (1854-1916 crops/s
             // against 1918-1943 with the full-occupancy plan).
-            h->wg_stream = rt::stream_create_low_priority();
+            static const bool wg_low = [] { const char* e = getenv("DR_WG_PRIO"); return !(e && e[0] == '0'); }();   // experiment: 0 = normal priority
+            h->wg_stream = wg_low ? rt::stream_create_low_priority() : rt::stream_create();
             h->wg_ready = rt::event_create_sync();
             h->wg_done = rt::event_create_sync();
         }

@@ -38,6 +38,7 @@ inline Event event_create_sync() { return Event{0}; }
 inline hipStream_t stream_create() { return (hipStream_t) nullptr; }         // the emulator runs every launch synchronously
 inline void stream_destroy(hipStream_t) {}
 inline hipStream_t stream_create_low_priority() { return (hipStream_t) nullptr; }
+inline hipStream_t stream_create_high_priority() { return (hipStream_t) nullptr; }
 inline void stream_wait_event(hipStream_t, Event) {}
 struct Graph { int dummy; };                                                  // no graphs on the emulator
 inline bool capture_begin(hipStream_t) { return false; }
@@ -85,6 +86,16 @@ inline hipStream_t stream_create_low_priority() {
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     hipStream_t s = nullptr;
     if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); return stream_create(); }
+    return s;
+}
+// highest-priority stream.  The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), least
+// used first, one pool PER PRIORITY LEVEL: two streams that must run concurrently (the micro-step slots, pipeline.inc) are safe
+// from sharing a queue with each other or with the caller's normal-priority streams when they alone populate a level.
+inline hipStream_t stream_create_high_priority() {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) != hipSuccess) { (void)hipGetLastError(); return stream_create(); }
     return s;
 }
 inline void stream_wait_event(hipStream_t s, Event ev) { (void)hipStreamWaitEvent(s, ev.e, 0); }

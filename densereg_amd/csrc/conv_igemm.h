@@ -79,7 +79,7 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned l
     return (z >> 17) & 1ull;
 }
 
-template <int BM, int BN, int WM, int WN, int BK_ = 16, int WK_ = 1>
+template <int BM, int BN, int WM, int WN, int BK_ = 16, int WK_ = 1, int MF_ = 32>
 struct ConvTile {
     static constexpr int kBK = BK_;
     static constexpr int kThreads = 256;
@@ -90,12 +90,12 @@ struct ConvTile {
     __host__ __device__ static constexpr int swz(int row) { return BK_ == 16 ? (row & 12) : ((row & 15) << 2); }
     static constexpr int kWTM = BM / WM;          // wave tile rows
     static constexpr int kWTN = BN / WN;
-    static constexpr int kTM = kWTM / 32;
-    static constexpr int kTN = kWTN / 32;
+    static constexpr int kTM = kWTM / MF_;        // MFMA output tiles of the wave tile (MF_ = 32: 32x32x2, 16: 16x16x4)
+    static constexpr int kTN = kWTN / MF_;
     static constexpr int kAIters = (BM * (kBK / 4)) / kThreads;
     static constexpr int kBIters = (BN * (kBK / 4) + kThreads - 1) / kThreads;
     static_assert(WM * WN * WK_ == 4, "4 waves per block");
-    static_assert(kWTM % 32 == 0 && kWTN % 32 == 0, "wave tile must be made of 32x32 MFMA tiles");
+    static_assert(kWTM % MF_ == 0 && kWTN % MF_ == 0, "wave tile must be made of whole MFMA tiles");
     static_assert((BM * (kBK / 4)) % kThreads == 0, "A loader mapping");
 };
 
@@ -132,13 +132,22 @@ constexpr int conv_min_waves() { return BK_ == 64 ? 2 : (BM * BN >= 128 * 128 ? 
 // roofline); here A is staged once, 640 workgroups of M = 40960 fall 2.5 per CU, and every fragment pair feeds 3 or 5 MFMAs.
 // XB = 1 (BF kernels): the A operand is stored as bf16 (ConvParams::x_bf16) -- a compile-time variant, because a run-time
 // branch around the staging loads keeps hipcc from issuing them as one batch.
-template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16, int GL = 0, int BF = 0, int WK = 1, int XB = 0>
-__global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<BM, BN, BK_>())) void conv_igemm_kernel(const ConvParams p) {
+// MF = 16 (narrow outputs in fp32: N = 65..80, 129..160; tiles 64x80, 64x144, 64x160): v_mfma_f32_16x16x4_f32 instead of 32x32x2 --
+// the same arithmetic per product and the same rate (64 flops per clock and SIMD), but output tiles of 16 columns, so a 78-
+// channel layer computes 80 columns instead of 96 and a 131-channel one 144 instead of 160.  The four waves are 4 row groups of
+// 16; each owns ALL BN columns (5 / 9 / 10 independent accumulator tiles): the A tile is staged once per workgroup where the
+// 128x32 tile re-staged it for every 32-column block and left each wave one accumulator chain.  Lane (r = lane & 15,
+// g = lane >> 4) feeds row / column r and, in MFMA step s, k = 4g + s: like the 32x32 path it fetches its four k with ONE
+// ds_read_b128 per operand tile and K-tile (which k a step pairs up is free as long as A and B agree).
+template <int BM, int BN, int WM, int WN, int ABL = 0, int BK_ = 16, int GL = 0, int BF = 0, int WK = 1, int XB = 0, int MF = 32>
+__global__ __launch_bounds__(256, (MF == 16 ? 5 : WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<BM, BN, BK_>())) void conv_igemm_kernel(const ConvParams p) {
+    static_assert(MF == 32 || (MF == 16 && BM == 64 && WM == 4 && WN == 1 && BK_ == 16 && GL == 0 && BF == 0 && WK == 1 && XB == 0 && ABL == 0),
+                  "16x16x4 variant: 64 rows x BN columns, fp32, register-staged refill");
     static_assert(XB == 0 || BF == 1, "bf16 storage of the A operand exists for the bf16 matrix-core kernels");
     static_assert(GL == 0 || (BK_ == 16 && BN >= 64 && BN % 64 == 0), "the LDS-DMA refill needs every wave's 64 lanes inside both tiles");
     static_assert(BF == 0 || (GL == 0 && BK_ == 16 && ABL == 0), "the bf16 variant exists for the register-staged 64-byte-row tile");
     static_assert(WK == 1 || (WK == 2 && BK_ == 16 && ABL == 0 && GL == 0), "K-split: two halves of a 16-k tile");
-    using T = ConvTile<BM, BN, WM, WN, BK_, WK>;
+    using T = ConvTile<BM, BN, WM, WN, BK_, WK, MF>;
     constexpr int BK = T::kBK;
     constexpr int SK = T::kSK;
     constexpr int CK = BF ? 32 : BK;      // input channels per K-tile
@@ -380,7 +389,9 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
     // nothing fills the gap).  Such tiles accumulate alternate k-steps into KACC independent accumulators that are
     // summed, in a fixed order, after the K loop.
     constexpr int KACC = (T::kTM * T::kTN == 1) ? (BK == 64 ? 4 : 2) : 1;
-    dr_f32x16 accp[KACC][T::kTM][T::kTN];
+    using AccT = typename std::conditional<MF == 16, dr_f32x4, dr_f32x16>::type;
+    constexpr int NR = MF == 16 ? 4 : 16;              // accumulator registers per lane and MFMA tile
+    AccT accp[KACC][T::kTM][T::kTN];
 #pragma unroll
     for (int q = 0; q < KACC; ++q)
 #pragma unroll
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
 #pragma unroll
             for (int j = 0; j < T::kTN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) accp[q][i][j][r] = 0.f;
+                for (int r = 0; r < NR; ++r) accp[q][i][j][r] = 0.f;
 
     bool tail0 = CK > p.Cin;
     load_tile(0);
@@ -406,6 +417,21 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
         const bool more = ABL != 1 && ABL < 6 && more_;                   // ABL 6..8: no refills, and (6) no barrier, (7) fragments read once, (8) both
         const bool was_tail = ld_kc + CK > p.Cin;                           // of the tile being fetched now
         if (more && ABL != 5) load_tile(buf ^ 1);
+        if constexpr (MF == 16) {
+            // lane (r16, g): row wm*16 + r16 of A, rows j*16 + r16 of B, the four k of slot g
+            const int r16 = lane & 15, g16 = lane >> 4;
+            const float4 a16 = *reinterpret_cast<const float4*>(&DR_AS(buf)[wm * 16 + r16][(g16 * 4) ^ T::swz(r16)]);
+#pragma unroll
+            for (int j = 0; j < T::kTN; ++j) {
+                const float4 b16 = *reinterpret_cast<const float4*>(&DR_BS(buf)[j * 16 + r16][(g16 * 4) ^ T::swz(r16)]);
+                accp[0][0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a16.x, b16.x, accp[0][0][j], 0, 0, 0);
+                accp[0][0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a16.y, b16.y, accp[0][0][j], 0, 0, 0);
+                accp[0][0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a16.z, b16.z, accp[0][0][j], 0, 0, 0);
+                accp[0][0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a16.w, b16.w, accp[0][0][j], 0, 0, 0);
+            }
+            if (more) store_tile(buf ^ 1, was_tail);
+            __syncthreads();
+        } else {
         // WK = 2: this wave multiplies only the k-slot group g = wk of the tile (the other half belongs to its partner wave)
         constexpr int NG = BK / 8 / WK;                          // fragment groups per wave and K-tile
         float4 a4[NG][T::kTM], b4[NG][T::kTN];                   // every fragment of this K-tile, read up front
@@ -457,6 +483,7 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
             if constexpr (!GL) store_tile(buf ^ 1, was_tail);
         }
         if (ABL != 6 && ABL < 8) __syncthreads();                         // ABL 9 = 8 + no epilogue stores
+        }
     };
     // Pairs of K-tiles run unconditionally (a K-tile under "if (t < T_total)" made hipcc carry the accumulators
     // in VGPRs and copy all of them to and from the AGPRs around every MFMA block); an odd last tile follows.
@@ -466,7 +493,7 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
         k_tile(1, t + 2 < T_total);
     }
     if (T_total & 1) k_tile(0, false);
-    dr_f32x16 acc[T::kTM][T::kTN];
+    AccT acc[T::kTM][T::kTN];
 #pragma unroll
     for (int i = 0; i < T::kTM; ++i)
 #pragma unroll
@@ -507,20 +534,25 @@ __global__ __launch_bounds__(256, (WK > 1 ? (BN > 96 ? 3 : 4) : conv_min_waves<B
     const unsigned ep_rows = (WK > 1 && wk != 0) ? 0u : 0xFFFFu;       // K-split: the wk = 0 wave holds the sums
     // one batch of 16 rows where the register budget allows it (three or two waves per SIMD), two of 8 in the five-wave kernels (16
     // spilled there: 60-72 bytes of scratch per lane)
-    constexpr int EP_BATCH_ROWS = (BM * BN >= 128 * 128 || BK_ == 64) ? 16 : 8;
+    constexpr int EP_BATCH_ROWS = MF == 16 ? 4 : (BM * BN >= 128 * 128 || BK_ == 64) ? 16 : 8;
+    constexpr int EP_TS = MF, EP_NR = NR;
+    const int ep_lg = MF == 16 ? (lane >> 4) : lk, ep_lc = MF == 16 ? (lane & 15) : li;
 #include "conv_epilogue.inc"
     if (p.stat_part) {
         // wave partials -> LDS (the operand tiles are dead: the K loop ended on a barrier) -> one row per workgroup
-        // [2][WM][BN] doubles: in the first A stage (K-split tiles: wider than tall, in the first B stage)
-        double* red = reinterpret_cast<double*>(WK > 1 ? &Bs0[0][0] : &As0[0][0]);
-        static_assert((WK > 1 ? sizeof(Bs0) : sizeof(As0)) >= sizeof(double) * 2 * WM * BN, "stat scratch does not fit the operand tile");
+        // [2][WM][BN] doubles: in the first A stage (K-split and 16-column tiles: wider than tall, in the first B stage)
+        double* red = reinterpret_cast<double*>((WK > 1 || MF == 16) ? &Bs0[0][0] : &As0[0][0]);
+        static_assert(((WK > 1 || MF == 16) ? sizeof(Bs0) : sizeof(As0)) >= sizeof(double) * 2 * WM * BN, "stat scratch does not fit the operand tile");
 #pragma unroll
         for (int j = 0; j < T::kTN; ++j) {
             double a = s1[j], b = s2[j];
+            if constexpr (MF == 16) {                                       // four lane groups hold four rows each of column lane & 15
+                a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+            }
             a += __shfl_xor(a, 32);
             b += __shfl_xor(b, 32);
-            if (lk == 0 && wk == 0) {                                       // (K-split: the partner wave accumulated nothing)
-                const int col = wn * T::kWTN + j * 32 + li;
+            if (ep_lg == 0 && wk == 0) {                                    // (K-split: the partner wave accumulated nothing)
+                const int col = wn * T::kWTN + j * MF + ep_lc;
                 red[(0 * WM + wm) * BN + col] = a;
                 red[(1 * WM + wm) * BN + col] = b;
             }

@@ -187,6 +187,8 @@ __global__ __launch_bounds__(256, 2) void conv_splitk_kernel(const ConvParams p)
     const int ep_m0 = m0, ep_n0 = n0;
     const unsigned ep_rows = 0xFu << (4 * wave);
     constexpr int EP_BATCH_ROWS = 16;     // two waves per SIMD by launch bounds: room for the whole column in one batch
+    constexpr int EP_TS = 32, EP_NR = 16;
+    const int ep_lg = lk, ep_lc = li;
 #include "conv_epilogue.inc"
 
     if (p.stat_part) {

@@ -51,7 +51,7 @@ static inline int grid_for(long total, int block = 256, int cap = 0) {
 // ==============================================================================================
 namespace dr {
 
-template <int BM, int BN, int WM, int WN, int BK = 16, int GL = 0, int BF = 0, int WK = 1>
+template <int BM, int BN, int WM, int WN, int BK = 16, int GL = 0, int BF = 0, int WK = 1, int MF = 32>
 static void launch_cfg(const ConvParams& p_in, hipStream_t s) {
     // N blocks of a row block back to back in dispatch order (conv_igemm.h nfast); DR_CONV_NFAST=0: plain 2-D grid order
     static const int nfast = [] { const char* e = getenv("DR_CONV_NFAST"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -59,11 +59,17 @@ static void launch_cfg(const ConvParams& p_in, hipStream_t s) {
     p.nfast = nfast;
     const int M = p.B * p.H * p.W;
     dim3 grid(dr_ceil_div(M, BM), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, BN));
-    p.gx = (int)grid.x; p.gy = (int)grid.y;
-    if constexpr (BF == 1) {
-        if (p.x_bf16) { DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK, 1>), grid, dim3(256), 0, s, p); return; }
+    if constexpr (MF == 16) {                                  // one column block spans every output channel (conv_tile_id): the 32-row
+        grid.y = 1;                                            // padding of the packed weights beyond it is never computed
+        p.gx = (int)grid.x; p.gy = 1;
+        DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK, 0, 16>), grid, dim3(256), 0, s, p);
+    } else {
+        p.gx = (int)grid.x; p.gy = (int)grid.y;
+        if constexpr (BF == 1) {
+            if (p.x_bf16) { DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK, 1>), grid, dim3(256), 0, s, p); return; }
+        }
+        DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK, 0>), grid, dim3(256), 0, s, p);
     }
-    DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK, 0>), grid, dim3(256), 0, s, p);
 }
 
 // LDS-DMA refill variant (conv_igemm.h GL) for inputs made of whole 16-byte channel chunks; DR_CONV_GLDS=0 selects the
@@ -107,6 +113,18 @@ int conv_tile_id(const ConvParams& p) {
         return KID_CONV_64x128;
     }
     if (ncols % 64 == 0) return (rows128 * (ncols / 64) >= 4096) ? KID_CONV_128x64 : KID_CONV_64x64;
+    // fp32, 65..80 and 129..160 output channels (the hm3 / um-head residuals and their input gradients: 65, 78, 131, 156 with
+    // J = 14): 16-column MFMA tiles, one 64-row workgroup spans all columns (conv_igemm.h, MF = 16) -- 80 / 144 computed columns
+    // where 32-column tiles pad to 96 / 160.  Measured at B = 40 against the 128x32 tile (profiles/r03_experiments.md): 3x3
+    // 78->78 77.9 -> 67.5 us, 3x3 65->65 77.7 -> 67.3, 1x1 156->78 24.0 -> 21.4, 1x1 256->78 33.1 -> 29.6, 1x1 128->131 32.0 ->
+    // 29.3, 1x1 256->156 52.9 -> 50.6; where 16 columns save nothing (MSRA's 85 -> 96, 105 -> 112, 170 -> 176) the tiles measured
+    // equal and are not built.  DR_CONV_MF16=0 restores the 128x32 tile.
+    if (!p.bf16 && p.Cout > 64) {
+        static const bool mf16 = [] { const char* e = getenv("DR_CONV_MF16"); return !(e && e[0] == '0'); }();
+        const int c16 = dr_round_up(p.Cout, 16);
+        if (mf16 && (c16 == 80 || c16 == 144 || c16 == 160) && ncols >= c16)
+            return c16 == 80 ? KID_CONV16_64x80 : c16 == 144 ? KID_CONV16_64x144 : KID_CONV16_64x160;
+    }
     // narrow outputs (N = 65..96, 129..160: the hm3 / um-head residuals and their input gradients) on grids that fill the
     // chip: one 64-row workgroup spans all columns, its four waves split rows and K (conv_igemm.h, WK); DR_CONV_NARROW=0 off
     static const bool narrow = [] { const char* e = getenv("DR_CONV_NARROW"); return !(e && e[0] == '0'); }();
@@ -123,7 +141,8 @@ int conv_stat_rows(const ConvParams& p) {
     const int M = p.B * p.H * p.W;
     const int t = conv_tile_id(p);
     if (t == KID_CONV_SPLITK) return dr_ceil_div(M, 32);
-    return dr_ceil_div(M, (t == KID_CONV_64x128 || t == KID_CONV_64x64 || t == KID_CONV_64x64_K64 || t == KID_CONV_64x96 || t == KID_CONV_64x160) ? 64 : 128);
+    return dr_ceil_div(M, (t == KID_CONV_64x128 || t == KID_CONV_64x64 || t == KID_CONV_64x64_K64 || t == KID_CONV_64x96 || t == KID_CONV_64x160 ||
+                           (t >= KID_CONV16_64x80 && t <= KID_CONV16_64x160)) ? 64 : 128);
 }
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
@@ -168,6 +187,9 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         case KID_CONV_64x64_K64: launch_cfg<64, 64, 2, 2, 64>(p, s); break;
         case KID_CONV_64x96: launch_cfg<64, 96, 2, 1, 16, 0, 0, 2>(p, s); break;
         case KID_CONV_64x160: launch_cfg<64, 160, 2, 1, 16, 0, 0, 2>(p, s); break;
+        case KID_CONV16_64x80: if (p.Cout > 80) return -1; launch_cfg<64, 80, 4, 1, 16, 0, 0, 1, 16>(p, s); break;
+        case KID_CONV16_64x144: if (p.Cout > 144) return -1; launch_cfg<64, 144, 4, 1, 16, 0, 0, 1, 16>(p, s); break;
+        case KID_CONV16_64x160: if (p.Cout > 160) return -1; launch_cfg<64, 160, 4, 1, 16, 0, 0, 1, 16>(p, s); break;
         default: launch_cfg<128, 32, 4, 1>(p, s); break;
     }
     return 0;

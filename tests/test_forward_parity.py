@@ -84,6 +84,43 @@ def test_conv_splitk_kernel_fused_epilogue(be, case, tile):
     np.testing.assert_allclose(st[1], (raw ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-4)
 
 
+MF16_CASES = [            # (B, H, W, Cin, Cout, k): output widths of the 16-column tiles, ragged and full, odd images, short / long K
+    (1, 9, 7, 156, 78, 1), (2, 5, 6, 78, 78, 3), (1, 8, 8, 131, 65, 1), (1, 7, 9, 65, 65, 3), (2, 6, 6, 64, 80, 1),
+    (1, 5, 5, 170, 131, 1), (1, 6, 7, 33, 142, 3), (2, 4, 9, 259, 129, 1), (1, 8, 5, 78, 156, 1), (1, 3, 3, 19, 160, 3), (3, 11, 3, 4, 145, 1),
+]
+
+
+@pytest.mark.parametrize('case', MF16_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_16_column_mfma_tiles(be, case):
+    """The fp32 tiles on v_mfma_f32_16x16x4_f32 (conv_igemm.h, MF = 16: 64 rows x 80 / 144 / 160 columns, what the launcher
+    now selects for 65..80 and 129..160 output channels on grids that fill the chip) with every fused epilogue feature -- scale /
+    shift, ReLU, residual, input row mask, BatchReNorm statistics -- against the fp64 definition, next to the heuristic's choice
+    and the 128x32 tile (DR_CONV_MF16=0's choice) on the same problem."""
+    B, H, W, Cin, Cout, k = case
+    rng = np.random.default_rng(hash(case) % 2**31 + 5)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
+    mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if k == 1 else None
+    tile = {80: 9, 144: 10, 160: 11}[-(-Cout // 16) * 16]
+    outs = {}
+    for t in (-1, tile, 4):
+        try:
+            assert be.dbg.dr_dbg_force_tile(t) == 0
+            outs[t] = be.conv2d(x, w, scale, shift, True, res, mask, -0.5, want_stats=True)
+        finally:
+            be.dbg.dr_dbg_force_tile(-1)
+    yr, raw = ref_conv2d(x, w, scale, shift, True, res, mask, -0.5)
+    for t, (y, st) in outs.items():
+        assert _rel(y, yr) < 2e-5, t
+        np.testing.assert_allclose(st[0], raw.sum((0, 1, 2)), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(st[1], (raw ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-4)
+    # (at these sizes the heuristic (-1) still prefers the split-K kernel: grids of a few workgroups; at B=40 x 32x32 it selects
+    # the 16-column tiles -- the whole-network B=40 parity tests of test_gpu_configs.py / test_gpu_fullsize.py run through them)
+
+
 def test_conv_transpose_detecting(be):
     """A = identity-like input with an ASYMMETRIC weight matrix: catches a swapped MFMA C/D layout."""
     Cin = Cout = 64
@@ -102,13 +139,13 @@ def test_conv_golden_vectors(be):
         assert _rel(y, g['y%d' % i]) < 2e-5
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_conv_every_tile_shape(be, tile):
     """Each tile configuration of the implicit-GEMM kernel (the heuristic only exercises some per shape)."""
     rng = np.random.default_rng(tile)
-    np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32, 5: 64, 6: 32, 7: 96, 8: 160}[tile]   # 5 = 64x64 tile with the fat (BK = 64) K-tile,
-                                                                             # 6 = 32x32 tile, K split over the four waves,
-                                                                             # 7 / 8 = 64x96 / 64x160, waves = 2 rows x 2 K halves
+    np_needed = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32, 5: 64, 6: 32, 7: 96, 8: 160, 9: 80, 10: 144, 11: 160}[tile]
+    # 5 = 64x64 tile with the fat (BK = 64) K-tile, 6 = 32x32 tile, K split over the four waves, 7 / 8 = 64x96 / 64x160, waves =
+    # 2 rows x 2 K halves, 9 / 10 / 11 = 64x80 / 64x144 / 64x160 on v_mfma_f32_16x16x4_f32 (four waves = four 16-row groups)
     Cout, Cin, k = np_needed - 3, 37, 3
     x = rng.standard_normal((1, 9, 15, Cin)).astype(np.float32)          # 135 rows: ragged last M tile
     w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
@@ -166,7 +203,9 @@ def test_conv_seeded_shape_sweep(be):
         Cin = int(rng.choice([1, 3, 4, 16, 19, 33, 64, 70, 131]))
         Cout = int(rng.choice([1, 5, 14, 32, 42, 65, 78, 96, 128, 131, 160, 170]))
         np_ = -(-Cout // 32) * 32
-        tiles = [-1, 4, 6] + ([2, 3, 5] if np_ % 64 == 0 else []) + ([0, 1] if np_ % 128 == 0 else []) + ([7] if np_ == 96 else []) + ([8] if np_ == 160 else [])
+        c16 = -(-Cout // 16) * 16
+        tiles = [-1, 4, 6] + ([2, 3, 5] if np_ % 64 == 0 else []) + ([0, 1] if np_ % 128 == 0 else []) + ([7] if np_ == 96 else []) + ([8] if np_ == 160 else []) + \
+            ([{80: 9, 144: 10, 160: 11}[c16]] if (Cout > 64 and c16 in (80, 144, 160)) else [])
         tile = int(rng.choice(tiles))
         x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
         w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)

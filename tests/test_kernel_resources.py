@@ -20,7 +20,9 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy():
     spills = [(n, r['scratch']) for n, r in rows if r.get('scratch', 0) > 0]
     assert not spills, spills
     occ = {n: r['occ'] for n, r in rows}
-    for name in ('dr::conv_igemm_kernel<64, 128, 2, 2, 0, 16, 1, 0, 1, 0>', 'dr::conv_igemm_kernel<64, 64, 2, 2, 0, 16, 1, 0, 1, 0>',
-                 'dr::conv_igemm_kernel<128, 32, 4, 1, 0, 16, 0, 0, 1, 0>', 'dr::conv_igemm_kernel<64, 128, 2, 2, 0, 16, 0, 1, 1, 0>'):
+    for name in ('dr::conv_igemm_kernel<64, 128, 2, 2, 0, 16, 1, 0, 1, 0, 32>', 'dr::conv_igemm_kernel<64, 64, 2, 2, 0, 16, 1, 0, 1, 0, 32>',
+                 'dr::conv_igemm_kernel<128, 32, 4, 1, 0, 16, 0, 0, 1, 0, 32>', 'dr::conv_igemm_kernel<64, 128, 2, 2, 0, 16, 0, 1, 1, 0, 32>',
+                 'dr::conv_igemm_kernel<64, 144, 4, 1, 0, 16, 0, 0, 1, 0, 16>', 'dr::conv_igemm_kernel<64, 160, 4, 1, 0, 16, 0, 0, 1, 0, 16>'):
         assert occ.get(name) == 5, (name, occ.get(name))
+    assert occ.get('dr::conv_igemm_kernel<64, 80, 4, 1, 0, 16, 0, 0, 1, 0, 16>', 0) >= 5
     assert occ['dr::conv_wgrad_kernel<128>'] >= 3 and occ['dr::bn_train_apply_kernel<0>'] >= 5

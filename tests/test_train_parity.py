@@ -262,7 +262,7 @@ def test_grouped_small_layer_wgrad_matches_per_layer_launches(be, monkeypatch):
         h.load_params(params)
         h.call('dr_finalize_params', be.stream)
         out = []
-        for Bn in (B, B, B - 1):
+        for Bn in ((B, B - 1) if be.name == 'emu' else (B, B, B - 1)):       # (emulator: CPU time)
             d_dm, d_pose, d_cfg, d_com, d_lo = (be.dev(np.ascontiguousarray(a[:Bn])) for a in (ndm, poses, cfgs, coms, np.zeros((B, 4), np.float32)))
             h.call('dr_forward_train', Bn, be.ptr(d_dm), 0, None, C.c_uint64(0), be.stream)
             h.call('dr_loss', Bn, be.ptr(d_dm), be.ptr(d_pose), be.ptr(d_cfg), be.ptr(d_com), be.ptr(d_lo), be.stream)
@@ -281,12 +281,13 @@ def test_grouped_small_layer_wgrad_matches_per_layer_launches(be, monkeypatch):
     for ga, gb in zip(inline, grouped):
         for n in ga:
             assert np.abs(ga[n] - gb[n]).max() / (np.abs(gb[n]).max() + 1e-12) < 2e-5, n
-    monkeypatch.setenv('DR_BN_LOOKBACK', '1')             # opt-in (measured slower on MI355X), kept correct
-    lookback = run(True)
-    monkeypatch.delenv('DR_BN_LOOKBACK')
-    for ga, gb in zip(lookback, grouped):
-        for n in ga:
-            assert np.abs(ga[n] - gb[n]).max() / (np.abs(gb[n]).max() + 1e-12) < 2e-5, n
+    if be.name == 'gpu':                                  # (the hand-off's kernels are covered on the emulator by test_bn_layer.py)
+        monkeypatch.setenv('DR_BN_LOOKBACK', '1')         # opt-in (measured slower on MI355X), kept correct
+        lookback = run(True)
+        monkeypatch.delenv('DR_BN_LOOKBACK')
+        for ga, gb in zip(lookback, grouped):
+            for n in ga:
+                assert np.abs(ga[n] - gb[n]).max() / (np.abs(gb[n]).max() + 1e-12) < 2e-5, n
     differs = 0
     for ga, gb in zip(grouped, single):
         for n in ga:

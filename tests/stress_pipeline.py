@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Run-to-run stability of the two-slot pipeline: the trajectory of tests/test_pipeline.py N times at depth 1 and 2, checksums of
-losses / moving statistics / parameters per run.  python tools/pipeline_stress.py [runs]"""
+losses / moving statistics / parameters per run.  python tests/stress_pipeline.py [runs]"""
 import os
 import sys
 

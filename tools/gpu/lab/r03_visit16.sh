@@ -11,4 +11,4 @@ for r in 2 3; do timeout 400 python bench.py --mode infer --replicas $r --no-cpu
 import json;d=json.load(open('$G/v16_i$r.json'));print('infer x$r',round(d['value'],1))"; done
 DR_PIPE_PRIO=1 timeout 300 python bench.py --no-cpu-baseline --no-profile --no-forward-vote --steps 50 --warmup 10 --precision bf16 | python -c "
 import json,sys;d=json.loads(sys.stdin.read());print('bf16 prio1',round(d['value'],1))"
-python tools/pipeline_stress.py 4 2>&1 | grep depth | cut -c1-120
+python tests/stress_pipeline.py 4 2>&1 | grep depth | cut -c1-120

@@ -668,7 +668,6 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         h->fuse_bn_bwd = !(fuse && fuse[0] == '0');
         const char* grp = getenv("DR_GROUP_WGRAD");
         h->group_wgrad = !(grp && grp[0] == '0');
-        // opt-in: measured slower on MI355X (train_kernels.h, bn_handoff_wait) -- BatchReNorm 5.5 -> 8.1 ms per step
         const char* ws = getenv("DR_WGRAD_STREAM");
         // default on (DR_WGRAD_STREAM=0: every weight gradient inline on the caller's stream; n > 1: additionally release the
         // queue after every (n-1)-th layer -- measured worse: beside the full-resolution kernels the side work only competes:
@@ -688,6 +687,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         h->bf16_act = !(a16 && a16[0] == '0');
         const char* b16 = getenv("DR_BF16_DRAW");
         h->bf16_draw = !(b16 && b16[0] == '0');
+        // opt-in: measured slower on MI355X (train_kernels.h, bn_handoff_wait) -- BatchReNorm 5.5 -> 8.1 ms per step
         const char* lb = getenv("DR_BN_LOOKBACK");
         h->bn_lookback = lb && lb[0] == '1';
     }
@@ -944,6 +944,8 @@ int dr_set_precision(dr_handle* h, int precision) {
         if (h->pack_dev) { rt::dfree(h->pack_dev); h->pack_dev = nullptr; }     // the packing table depends on the element type
         h->precision = precision;
         h->finalized = false;                                                   // weights must be re-packed
+        for (auto& t : h->tensors) t->is_bf16 = false;                          // what a forward stored is void with the old precision
+        h->last_forward_train = false;
         for (auto& g : h->graphs) rt::graph_destroy(g.g);                       // recorded launches name the old kernels
         h->graphs.clear();
     }
@@ -1286,9 +1288,12 @@ int dr_read_activation(dr_handle* h, const char* scope, int B, float* host, size
         const size_t need = (size_t)M * op.out.C;
         if (count != need) DR_FAIL(h, DR_E_INVALID, "dr_read_activation: %s has %zu elements, got %zu", scope, need, count);
         if (need > h->n_scratch) DR_FAIL(h, DR_E_STATE, "scratch too small");
-        if (t->is_bf16) DR_FAIL(h, DR_E_STATE, "dr_read_activation: '%s' is stored as bf16 by the training forward on the bf16 path (DR_BF16_ACT=0 keeps fp32)", scope);
-        DR_LAUNCH(copy_channels_kernel, dim3(grid_for(M * op.out.C)), dim3(256), 0, (hipStream_t) nullptr, (const float*)t->p,
-                  t->cs, op.out.coff, h->scratch, op.out.C, 0, M, op.out.C, 0);
+        if (t->is_bf16)                     // stored as bf16 by the training forward of the bf16 path (its only reader is a conv): widen
+            DR_LAUNCH(copy_channels_from_bf16_kernel, dim3(grid_for(M * op.out.C)), dim3(256), 0, (hipStream_t) nullptr,
+                      reinterpret_cast<const __bf16*>(t->p), t->cs, op.out.coff, h->scratch, op.out.C, 0, M, op.out.C);
+        else
+            DR_LAUNCH(copy_channels_kernel, dim3(grid_for(M * op.out.C)), dim3(256), 0, (hipStream_t) nullptr, (const float*)t->p,
+                      t->cs, op.out.coff, h->scratch, op.out.C, 0, M, op.out.C, 0);
         rt::sync_stream(nullptr);
         rt::d2h(host, h->scratch, need * sizeof(float), nullptr);
         rt::sync_stream(nullptr);

@@ -155,6 +155,18 @@ __global__ __launch_bounds__(256) void zero_segments_kernel(float* base, const Z
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// bf16-stored source (element stride s_cs, as the BatchReNorm apply pass of the bf16 path leaves a single-reader activation) -> dense
+// fp32: what dr_read_activation hands out for such a tensor
+__global__ __launch_bounds__(256) void copy_channels_from_bf16_kernel(const __bf16* src, int s_cs, int s_coff, float* dst, int d_cs,
+                                                                      int d_coff, long M, int C) {
+    const long total = M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = int(i % C);
+        const long m = i / C;
+        dst[m * d_cs + d_coff + c] = (float)src[m * s_cs + s_coff + c];
+    }
+}
+
 __global__ __launch_bounds__(256) void copy_channels_kernel(const float* src, int s_cs, int s_coff, float* dst, int d_cs,
                                                             int d_coff, long M, int C, int accumulate) {
     if (((C | s_cs | s_coff | d_cs | d_coff) & 3) == 0) {                 // uniform: 16-byte rows on both sides

@@ -248,6 +248,35 @@ def test_train_step_bf16_default_width_runs(be):
     h.close()
 
 
+def test_read_activation_of_a_bf16_stored_tensor(be, monkeypatch):
+    """On the bf16 path the training forward stores a single-conv-reader activation as bf16 (DR_BF16_ACT); dr_read_activation
+    widens it instead of refusing (round-2 advisor finding): the values are the nearest-even bf16 of what a handle with
+    DR_BF16_ACT=0 holds in fp32."""
+    from oracle.graph import conv_specs
+    from tests.common import bf16_round
+    B = 3                                  # 12 288 pixels at 64x64: the reader runs on a tiled kernel, not the fp32-staging split-K one
+    cfg, params, ndm, poses, cfgs, coms = _case(1, 64, 4, B)
+    specs = conv_specs(cfg)
+    # the first conv of the stem's first residual module (1x1 32 -> 16 at 64x64): BatchReNorm + ReLU, read only by the module's 3x3 conv
+    name = [c.name for c in specs if c.bn and c.k == 1 and c.h_out == 64 and c.cout == 16][0]
+    shape = (B, 64, 64, 16)
+
+    def act(stored):
+        monkeypatch.setenv('DR_BF16_ACT', '1' if stored else '0')
+        h = be.handle(cfg, B, training=True)
+        h.call('dr_set_precision', 1)
+        h.load_params(params)
+        h.call('dr_finalize_params', be.stream)
+        d_dm = be.dev(ndm)
+        h.call('dr_forward_train', B, be.ptr(d_dm), 0, None, C.c_uint64(0), be.stream)
+        a = be.read_activation(h, name, shape)
+        h.close()
+        return a
+    a32, a16 = act(False), act(True)
+    assert np.isfinite(a16).all() and np.abs(a32).max() > 0
+    np.testing.assert_array_equal(a16, bf16_round(a32))
+
+
 def test_grouped_small_layer_wgrad_matches_per_layer_launches(be, monkeypatch):
     """Layers up to 16x16 pixels keep their dRaw in a private buffer and compute their weight gradients in ONE grouped
     launch at the end of the backward sweep (conv_wgrad_group_kernel; DR_GROUP_WGRAD=0 restores a launch per layer).

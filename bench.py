@@ -59,6 +59,9 @@ def parse():
     ap.add_argument('--dataset', default='', choices=['', 'icvl', 'nyu', 'msra'], help='default: nyu for train, icvl for infer')
     ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
                     help='matrix-core arithmetic of the convolutions; bf16 = BASELINE config 5\'s conv path (fp32 stays the headline)')
+    ap.add_argument('--groups', type=int, default=int(os.environ.get('DR_BENCH_GROUPS', '-1')),
+                    help='train mode: micro-steps of an accumulation window run as ONE pass of launches (dr_set_groups). '
+                         '-1 = auto (sub_batch where the engine supports it and the window fits), 1 = one micro-step per pass')
     ap.add_argument('--replicas', type=int, default=3,
                     help='forward(eval)+vote: inference replicas per GPU, consecutive batches alternate between them '
                          '(densereg_amd/serving.py; 1 = one engine, one stream)')
@@ -199,7 +202,15 @@ def main():
     dataset = args.dataset or ('nyu' if mode == 'train' else 'icvl')
     J = DATASETS[dataset]['jnt_num']
     S, F, B, HW = args.num_stack, args.num_fea, args.batch, args.in_hw
-    eng = Engine(S, F, J, HW, 3, B, local, training=(mode == 'train'))
+    # training: the `sub_batch` micro-steps between two optimizer steps as micro-batch groups of one pass (dr_set_groups) where
+    # the window fits comfortably: up to 262 144 pixels per full-resolution layer (5 x 40 crops at 32x32 maps: 204 800)
+    G = 1
+    if mode == 'train':
+        G = args.groups if args.groups >= 1 else (args.sub_batch if (2 <= args.sub_batch <= 8 and B % 8 == 0 and
+                                                                     B * args.sub_batch * (HW // 4) ** 2 <= 262144) else 1)
+        if G > 1 and (G != args.sub_batch or B % 8):
+            raise SystemExit('bench.py: --groups %d needs sub_batch == groups and a batch that is a multiple of 8' % G)
+    eng = Engine(S, F, J, HW, 3, B * G, local, training=(mode == 'train'))
     bf16 = args.precision == 'bf16'
     if bf16:
         eng.set_precision('bf16')
@@ -226,6 +237,11 @@ def main():
     d_dm = eng.norm_dm(d_dm_mm, d_com)
     xyz = eng.new(B, 3 * J)
     trainer = DataParallelTrainer(eng, dataset=dataset, sub_batch=args.sub_batch, dist=dist) if mode == 'train' else None
+    if G > 1:                                                # the G micro-batches of a window (different crops), resident like d_dm
+        wdm, wposes, wcfgs, wcoms, _ = make_crops(B * G, dataset, seed=20240, rank=rank, hw=HW)
+        w_pose, w_cfg, w_com = t(wposes), t(wcfgs), t(wcoms)
+        w_dm = eng.norm_dm(t(wdm), w_com)
+    pending = [0]                                            # micro-steps handed in since the last window / flush
 
     # forward(eval)+vote throughput: `--replicas` engines with the same weights, each on its own stream, take the batches in turn
     # (north-star: inference = replicas; the single-engine figure is reported next to it)
@@ -244,8 +260,19 @@ def main():
                 pool.submit(d_dm, d_cfg, d_com, out=pool_out[i % args.replicas])
             else:
                 eng.infer(d_dm, d_cfg, d_com, out=xyz)
+        elif G > 1:                                          # every G-th micro-step launches the window they form
+            pending[0] += 1
+            if pending[0] == G:
+                trainer.window_step(w_dm, w_pose, w_cfg, w_com, seed=i)
+                pending[0] = 0
         else:
             trainer.micro_step(d_dm, d_pose, d_cfg, d_com, seed=i)
+
+    def flush():
+        """micro-steps that do not fill a window (K or W not a multiple of G) run one by one: exactly K steps are timed"""
+        for _ in range(pending[0]):
+            trainer.micro_step(d_dm, d_pose, d_cfg, d_com, seed=0)
+        pending[0] = 0
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -257,10 +284,12 @@ def main():
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize, MAX over ranks (seconds)."""
         for i in range(args.warmup):
             fn(i)
+        flush()
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             fn(args.warmup + i)
+        flush()
         barrier()
         el = time.perf_counter() - t0
         if dist is not None:
@@ -281,8 +310,8 @@ def main():
     roof = None
     if not args.no_profile:
         eng.h.profile(True)
-        nprof = max(2, min(5, args.steps))
-        for i in range(nprof):
+        nprof = max(2, min(5, args.steps))                     # profiled passes (training with groups: whole windows)
+        for i in range(nprof * G):
             step(1000 + i)
         if args.detail and rank == 0:
             rows = sorted(eng.h.profile_detail(), key=lambda r: -r['total_ms'])
@@ -307,6 +336,7 @@ def main():
             roof = {'kernel': dom['name'], 'bound': 'mfma', 'achieved': ach, 'peak': peak,
                     'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic, 'traffic_provenance': traffic_prov,
                     'launches_per_step': dom['launches'] / nprof, 'avg_launch_us': dom['total_ms'] * 1e3 / dom['launches'],
+                    'micro_steps_per_profiled_step': G,
                     'algorithmic_gflop_per_launch': dom['flops'] / dom['launches'] / 1e9,
                     'share_of_step_time': dom['total_ms'] / max(sum(s['total_ms'] for s in stats), 1e-9),
                     # the runner-up family, same accounting (training: the forward/dgrad tile and the weight gradients trade places)
@@ -370,11 +400,13 @@ def main():
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': ('%s S=%d F=%d J=%d B=%d/GPU %dx%d ' % (dataset.upper(), S, F, J, B, HW, HW)) +
-                       ('train micro-step fwd+loss+bwd, RCCL all-reduce + clip + Adam every %d steps' % args.sub_batch
+                       ('train micro-step fwd+loss+bwd, RCCL all-reduce + clip + Adam every %d steps' % args.sub_batch +
+                        (' (the %d micro-batches of a window run as one pass of launches, BatchReNorm per micro-batch)' % G if G > 1 else '')
                         if mode == 'train' else 'forward(eval) + vote -> xyz mm') +
                        (', bf16 matrix cores on fp32 tensors (fp32 accumulate, epilogues, vote)' if bf16 else ''),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
                        'micro_steps_in_flight': eng_pipeline if mode == 'train' else None,
+                       'micro_steps_per_pass': G if mode == 'train' else None,
                        'replicas_per_gpu': args.replicas if mode == 'infer' else None, 'single_replica': single,
                        'world_size': dist.get_world_size() if dist is not None else 1, 'rccl_version': rccl,
                        'conv_gflop_per_crop_fwd': eng_flops / 1e9},

@@ -73,6 +73,7 @@ SIGNATURES = {
     'dr_backward': (_i, [_vp, _i, _vp]),
     'dr_zero_grad': (_i, [_vp, _vp]),
     'dr_set_pipeline': (_i, [_vp, _i]),
+    'dr_set_groups': (_i, [_vp, _i]),
     'dr_sync_grads': (_i, [_vp, _vp]),
     'dr_flat_grad': (_i, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
     'dr_flat_param': (_i, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),

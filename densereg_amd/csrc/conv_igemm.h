@@ -59,6 +59,10 @@ struct ConvParams {
     // g = dOut * bst_factor * [out > 0] (the gradient wrt the conv's pre-activation: its act_bwd pass disappears) and the
     // stat_part rows hold sum(g) = the bias gradient (its column-sum pass disappears too).
     int bst_act; float bst_factor;
+    // micro-batch groups (train_kernels.h, BnTrainParams): the output rows are consecutive micro-batches of grp_rows rows (a
+    // multiple of every tile's rows, so a workgroup lies in one group); group g's bst_scale / bst_shift are grp_fold floats
+    // behind group g-1's, its bst_bnc 2 * grp_fold floats.  0: one batch.
+    int grp_rows, grp_fold;
     int Ng;                                // > 0: compute only the first Ng (multiple of 32, <= Np) output columns -- Np
                                            // stays the row stride of the packed weights (input gradients of a concat
                                            // buffer whose last channels have no consumer)

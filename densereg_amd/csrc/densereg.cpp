@@ -85,10 +85,23 @@ static int g_force_tile = -1;        // test/bench hook (dr_dbg_conv_bench); -1 
 static int g_dbg_bf16 = 0;           // test/bench hook (dr_dbg_force_bf16): dr_dbg_conv2d / dr_dbg_conv_bench run the bf16 kernels
 static int g_dbg_bf16_storage = 0;   // test hook (dr_dbg_force_bf16_storage): bf16-stored x / g / draw in the debug entries
 
+static int conv_tile_heuristic(const ConvParams& p);
+static int tile_rows_of(int t) {
+    if (t == KID_CONV_SPLITK) return 32;
+    return (t == KID_CONV_64x128 || t == KID_CONV_64x64 || t == KID_CONV_64x64_K64 || t == KID_CONV_64x96 || t == KID_CONV_64x160 ||
+            (t >= KID_CONV16_64x80 && t <= KID_CONV16_64x160)) ? 64 : 128;
+}
 // tile shape for a problem (shared by the launcher and the profiler labels)
 int conv_tile_id(const ConvParams& p) {
-    const int M = p.B * p.H * p.W;
     if (g_force_tile >= 0) return g_force_tile;
+    const int t = conv_tile_heuristic(p);
+    // micro-batch groups: a workgroup's rows must lie in one group (per-group statistics rows, per-group coefficients) -- where
+    // the preferred tile straddles the boundaries (2x2 layers: 4 rows per crop) the 32-row split-K kernel takes the launch
+    if (p.grp_rows > 0 && p.grp_rows % tile_rows_of(t) != 0 && p.grp_rows % 32 == 0 && !p.x_bf16) return KID_CONV_SPLITK;
+    return t;
+}
+static int conv_tile_heuristic(const ConvParams& p) {
+    const int M = p.B * p.H * p.W;
     const int ncols = p.Ng > 0 ? p.Ng : p.Np;                 // output columns this launch computes
     // Measured on MI355X (profiles/r01_conv_microbench.md): what decides between the tiles of one N width is how
     // evenly the workgroups fall on the 256 CUs.  M = 40960 rows: Np = 256 / 512 give 1280 / 2560 64x128 workgroups
@@ -136,14 +149,10 @@ int conv_tile_id(const ConvParams& p) {
     return KID_CONV_128x32;
 }
 
+// output rows per workgroup of the tile a problem gets
+int conv_tile_rows(const ConvParams& p) { return tile_rows_of(conv_tile_id(p)); }
 // rows of ConvParams::stat_part the launch writes = workgroups along M of the chosen tile
-int conv_stat_rows(const ConvParams& p) {
-    const int M = p.B * p.H * p.W;
-    const int t = conv_tile_id(p);
-    if (t == KID_CONV_SPLITK) return dr_ceil_div(M, 32);
-    return dr_ceil_div(M, (t == KID_CONV_64x128 || t == KID_CONV_64x64 || t == KID_CONV_64x64_K64 || t == KID_CONV_64x96 || t == KID_CONV_64x160 ||
-                           (t >= KID_CONV16_64x80 && t <= KID_CONV16_64x160)) ? 64 : 128);
-}
+int conv_stat_rows(const ConvParams& p) { return dr_ceil_div(p.B * p.H * p.W, conv_tile_rows(p)); }
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     if (p.x_cs % 4 || p.x_coff % 4 || p.Kp % 16 || p.Np % 32 || !p.zeros || p.Ng % 32 || p.Ng > p.Np) return -1;
@@ -645,7 +654,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
     alloc_f(h->flat_param, nt);
     alloc_f(h->flat_state, ns);
     alloc_f(h->wp, nwp);
-    alloc_f(h->fold, nfold);
+    alloc_f(h->fold, nfold * (cfg->training ? (size_t)kMaxGroups : 1));      // training: one copy per micro-batch group (dr_set_groups)
     alloc_f(h->act_arena, h->n_act);
     alloc_f(h->scratch, h->n_scratch);
     h->scratch_l[0] = h->scratch;
@@ -697,7 +706,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
     }
     alloc_f(h->tiny, MB * h->map_hw * h->map_hw);
     alloc_f(h->tiny_ext, MB * h->map_hw * h->map_hw);
-    alloc_f(h->losses, 4);
+    alloc_f(h->losses, 4 * (size_t)kMaxGroups);
     alloc_f(h->zeros, 64);
     if (cfg->training) {
         alloc_f(h->flat_grad, nt);
@@ -706,7 +715,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         alloc_f(h->shadow, nsh);
         alloc_f(h->flat_state_next, ns);
         alloc_f(h->wpT, nwpT);
-        alloc_f(h->bnc, nbnc);
+        alloc_f(h->bnc, nbnc * (size_t)kMaxGroups);
         h->n_gact = nact;
         alloc_f(h->grad_arena, nact);
         if (ok && alloc_training_state(h)) ok = false;

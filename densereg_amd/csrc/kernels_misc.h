@@ -213,10 +213,13 @@ __global__ __launch_bounds__(256) void norm_dm_kernel(const float* dm, const flo
 // per-channel sum / sum of squares over M rows.  grid = (row chunks), block = 256.
 // thread -> channel (tid % Cg) and row phase; fp64 accumulation; one partial row per workgroup, part[2][C][gridDim.x], which
 // the BatchReNorm finalize folds in a fixed order (no floating-point atomics on the training path).
+// gridDim.y > 1: micro-batch groups of M rows each (blockIdx.y = group), partial rows [group][gridDim.x] side by side.
 __global__ __launch_bounds__(256) void moments_kernel(const float* x, int cs, int coff, long M, int C, double* part) {
     __shared__ double s1[256];
     __shared__ double s2[256];
     const int tid = threadIdx.x;
+    x += (long)blockIdx.y * M * cs;
+    const long prow = (long)blockIdx.y * gridDim.x + blockIdx.x, prows = (long)gridDim.x * gridDim.y;
     const int cpb = C < 256 ? C : 256;             // channels handled per pass
     const int rows_par = 256 / cpb;                // row phases
     for (int c0 = 0; c0 < C; c0 += cpb) {
@@ -236,8 +239,8 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, int cs, in
         if (tid < cpb && c0 + tid < C) {
             double ta = 0.0, tb = 0.0;
             for (int r = 0; r < rows_par; ++r) { ta += s1[r * cpb + tid]; tb += s2[r * cpb + tid]; }
-            part[(long)(c0 + tid) * gridDim.x + blockIdx.x] = ta;
-            part[((long)C + c0 + tid) * gridDim.x + blockIdx.x] = tb;
+            part[(long)(c0 + tid) * prows + prow] = ta;
+            part[((long)C + c0 + tid) * prows + prow] = tb;
         }
         __syncthreads();
     }

@@ -243,6 +243,7 @@ struct dr_handle {
     const float* dm_train = nullptr;                       // input of the last dr_forward_train
     // micro-step slots (StepSlot above)
     dr::StepSlot slot[2];
+    int groups = 1;                                        // micro-batch groups per call (dr_set_groups): 1 = the batch is one micro-batch
     int pipe_depth = 1;                                    // 1: every call runs on the caller's stream; 2: two micro-steps in flight
     int cur_slot = 0, next_slot = 0;                       // slot of the micro-step in progress / of the next dr_forward_train
     float* gacc = nullptr;                                 // gradient accumulator of the bound slot (slot 0's IS flat_grad)

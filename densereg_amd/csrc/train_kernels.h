@@ -42,7 +42,15 @@ struct BnTrainParams {
     int* flag; int flag_target;                 // look-back hand-off (bn_train_apply_kernel<2>): groups published so far / wanted
     int out_bf16;                               // out holds bf16 elements (same element stride out.cs; whole channel groups of four,
                                                 // no residual): the activation's only readers round it to bf16 while staging
+    // Micro-batch groups (dr_set_groups): the M rows are `groups` consecutive micro-batches of Mg rows each -- the reference's
+    // gradient-accumulation micro-steps (train_single_gpu.py:138-150) run as ONE pass of launches.  Statistics, r / d and the
+    // moving-state update are per micro-batch, in order (group g reads the moving statistics group g-1 left: ops.py:134-162);
+    // the partial rows of group g are rows [g*rows_per_group, (g+1)*rows_per_group) of `part`; scale | shift and bnc of group g
+    // live fold_stride / bnc_stride floats behind group g-1's.  groups <= 1: one batch, M rows (everything above as it was).
+    int groups; int rows_per_group; long Mg; long fold_stride; long bnc_stride;
+    float r_max_g[8], d_max_g[8];               // the schedule scalars of groups 0..groups-1 (r_max / d_max above = group 0's)
 };
+constexpr int kMaxGroups = 8;
 
 // Look-back hand-off of per-channel coefficients inside ONE launch instead of a separate finalize launch per layer and
 // sweep (~200 launches of 5-6 us per training step).  OPT-IN (DR_BN_LOOKBACK=1) and NOT the default: measured on MI355X it
@@ -96,6 +104,54 @@ __device__ __forceinline__ BnChanIn bn_channel_load(const BnTrainParams& p, int 
     in.sh_m = p.shadow_mean[c]; in.sh_v = p.shadow_var[c];
     return in;
 }
+// One micro-batch group of the chain: `in` carries the moving statistics / zero-debias accumulators the group reads and is
+// advanced to what it leaves behind; the group's scale | shift | bnc go to its own copy (gi * stride); the LAST group writes the
+// moving state back.  gi = 0, last = true, cnt = M, the handle's r_max / d_max: the single-batch case, bit for bit.
+__device__ __forceinline__ void bn_channel_coeffs_group(const BnTrainParams& p, int c, BnChanIn& in, double sum, double sq, double cnt, float r_max,
+                                                        float d_max, int gi, bool last) {
+    const float mm = in.mm, mv = in.mv, g = in.g, beta = in.beta, sh_m = in.sh_m, sh_v = in.sh_v;
+    const double mean_d = sum / cnt;
+    double var_d = sq / cnt - mean_d * mean_d;
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d, var = (float)var_d;
+    const float std_b = sqrtf(var + p.eps);
+    const float inv_std = 1.0f / std_b;
+    const float mstd = sqrtf(mv + p.eps);
+    float r = std_b / mstd;
+    r = fminf(fmaxf(r, 1.0f / r_max), r_max);
+    float d = (mean - mm) / mstd;
+    d = fminf(fmaxf(d, -d_max), d_max);
+    const float sc = inv_std * r;
+    float* scale = p.scale + (long)gi * p.fold_stride;
+    float* shift = p.shift + (long)gi * p.fold_stride;
+    float* bnc = p.bnc + (long)gi * p.bnc_stride;
+    scale[c] = sc * g;
+    shift[c] = (d - mean * sc) * g + beta;
+    bnc[0 * p.C + c] = mean;
+    bnc[1 * p.C + c] = inv_std;
+    bnc[2 * p.C + c] = r;
+    bnc[3 * p.C + c] = d;
+    const float om = 1.0f - p.decay;
+    float mm_new, mv_new;
+    if (p.shadow_step > 0) {
+        const float bm = sh_m - (sh_m - mean) * om;
+        const float bv = sh_v - (sh_v - var) * om;
+        in.sh_m = bm; in.sh_v = bv;
+        const float corr = 1.0f - powf(p.decay, (float)(p.shadow_step + gi));
+        mm_new = bm / corr;
+        mv_new = bv / corr;
+    } else {
+        mm_new = mm - (mm - mean) * om;
+        mv_new = mv - (mv - var) * om;
+    }
+    in.mm = mm_new; in.mv = mv_new;
+    if (last) {
+        if (p.shadow_step > 0) { p.shadow_mean[c] = in.sh_m; p.shadow_var[c] = in.sh_v; }
+        p.mm_next[c] = mm_new;
+        p.mv_next[c] = mv_new;
+    }
+}
+
 __device__ __forceinline__ void bn_channel_coeffs(const BnTrainParams& p, int c, const BnChanIn& in, double sum, double sq, float& sc_out, float& sh_out,
                                                   bool persist) {
     const float mm = in.mm, mv = in.mv, g = in.g, beta = in.beta, sh_m = in.sh_m, sh_v = in.sh_v;
@@ -140,10 +196,15 @@ __device__ __forceinline__ void bn_channel_coeffs(const BnTrainParams& p, int c,
 // Fold the per-workgroup partials of the conv epilogue / the backward reduce and derive everything the step
 // needs per channel.  Partials are stored [2][C][rows] -- the rows of one channel are contiguous -- so one wave folds
 // one channel with coalesced loads and a fixed shuffle tree (reproducible); block = 4 waves = 4 channels.
+// rows [row0, row0 + nrows) of the `rows_total` partial rows of channel c (a micro-batch group's share; the whole range otherwise)
+__device__ __forceinline__ void fold_partials_wave(const double* part, int rows_total, int C, int c, int row0, int nrows, double& sum, double& sq);
 __device__ __forceinline__ void fold_partials_wave(const double* part, int rows, int C, int c, double& sum, double& sq) {
+    fold_partials_wave(part, rows, C, c, 0, rows, sum, sq);
+}
+__device__ __forceinline__ void fold_partials_wave(const double* part, int rows_total, int C, int c, int row0, int rows, double& sum, double& sq) {
     const int lane = threadIdx.x & 63;
-    const double* pa = part + (long)c * rows;
-    const double* pb = part + ((long)C + c) * rows;
+    const double* pa = part + (long)c * rows_total + row0;
+    const double* pb = part + ((long)C + c) * rows_total + row0;
     double a = 0.0, b = 0.0;
     // eight rows per lane and operand in flight, unconditional (clamped row; the value of a row past the end is dropped): a tail
     // loop of single loads was a round trip per 64 rows -- with the 640 rows of a 32x32 layer four trips where one does
@@ -191,6 +252,16 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const BnTrainParam
     DR_PIN_ARGS(p.part, p.part_rows, p.C, p.M, p.beta, p.gamma, p.mm, p.mv, p.mm_next, p.mv_next, p.shadow_mean, p.shadow_var, p.shadow_step, p.scale, p.shift, p.bnc);
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= p.C) return;
+    if (p.groups > 1) {                                   // micro-batch groups: the chain of their state updates, in order
+        BnChanIn st = bn_channel_load(p, c);
+        for (int g = 0; g < p.groups; ++g) {
+            double sum, sq;
+            fold_partials_wave(p.part, p.part_rows, p.C, c, g * p.rows_per_group, p.rows_per_group, sum, sq);
+            if ((threadIdx.x & 63) == 0)
+                bn_channel_coeffs_group(p, c, st, sum, sq, (double)p.Mg, p.r_max_g[g], p.d_max_g[g], g, g == p.groups - 1);
+        }
+        return;
+    }
     const BnChanIn in = bn_channel_load(p, c);
     double sum, sq;
     fold_partials_wave(p.part, p.part_rows, p.C, c, sum, sq);
@@ -205,8 +276,18 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const BnTrainParam
 // MODE 0: coefficients come from a bn_fwd_finalize_kernel launch; 1 (FUSE): few partial rows, every workgroup folds them;
 // 2: look-back hand-off (above).
 template <int MODE>
-__global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams p) {
-    DR_PIN_ARGS(p.raw, p.raw_cs, p.M, p.C, p.scale, p.shift, p.relu, p.res.p, p.res.cs, p.res.coff, p.out.p, p.out.cs, p.out.coff, p.out_bf16, p.part, p.part_rows, (int)gridDim.x);
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams p_in) {
+    DR_PIN_ARGS(p_in.raw, p_in.raw_cs, p_in.M, p_in.C, p_in.scale, p_in.shift, p_in.relu, p_in.res.p, p_in.res.cs, p_in.res.coff, p_in.out.p, p_in.out.cs, p_in.out.coff, p_in.out_bf16, p_in.part, p_in.part_rows, (int)gridDim.x);
+    BnTrainParams p = p_in;
+    if (MODE == 0 && p.groups > 1) {                      // blockIdx.y = micro-batch group: its rows, its coefficients
+        const long g = blockIdx.y, r0 = g * p.Mg;
+        p.raw += r0 * p.raw_cs;
+        if (p.res.p) p.res.p += r0 * p.res.cs;
+        if (p.out_bf16) p.out.p = reinterpret_cast<float*>(reinterpret_cast<__bf16*>(p.out.p) + r0 * p.out.cs);
+        else p.out.p += r0 * p.out.cs;
+        p.scale += g * p.fold_stride; p.shift += g * p.fold_stride;
+        p.M = p.Mg;
+    }
     constexpr bool FUSE = MODE == 1;
     __shared__ float s_sc[FUSE ? 1024 : 1], s_sh[FUSE ? 1024 : 1];
     // MODE 2: the grid is [ceil(C/4) producer workgroups | the streaming workgroups].  A producer folds its four channels,
@@ -336,10 +417,22 @@ struct BnBwdParams {
     int draw_bf16;                    // draw holds bf16 elements (same element stride raw_cs): both of its readers -- the layer's
                                       // dgrad and weight gradient on the bf16 matrix cores -- round it to bf16 anyway
                                       // while staging, so the numbers are the same and the tensor is half the bytes
+    // micro-batch groups (BnTrainParams): per-group sums, coefficients (coef of group g: 3*C floats behind group g-1's) and
+    // forward values (scale | shift, bnc copies fold_stride / bnc_stride floats apart); dbeta / dgamma sum over the groups
+    int groups; int rows_per_group; long Mg; long fold_stride; long bnc_stride;
 };
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p) {
-    DR_PIN_ARGS(p.dout.p, p.dout.cs, p.dout.coff, p.raw, p.raw_cs, p.M, p.C, p.relu, p.scale, p.shift, p.bnc, p.part, (int)gridDim.x);
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p_in) {
+    DR_PIN_ARGS(p_in.dout.p, p_in.dout.cs, p_in.dout.coff, p_in.raw, p_in.raw_cs, p_in.M, p_in.C, p_in.relu, p_in.scale, p_in.shift, p_in.bnc, p_in.part, (int)gridDim.x);
+    BnBwdParams p = p_in;
+    int part_row = (int)blockIdx.x, part_rows = (int)gridDim.x;
+    if (p.groups > 1) {                                   // blockIdx.y = micro-batch group
+        const long g = blockIdx.y, r0 = g * p.Mg;
+        p.dout.p += r0 * p.dout.cs; p.raw += r0 * p.raw_cs;
+        p.scale += g * p.fold_stride; p.shift += g * p.fold_stride; p.bnc += g * p.bnc_stride;
+        p.M = p.Mg;
+        part_row += (int)g * (int)gridDim.x; part_rows *= (int)gridDim.y;
+    }
     __shared__ double s1[256 * 4];
     __shared__ double s2[256 * 4];
     const int c4n = p.raw_cs / 4;
@@ -406,8 +499,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
             if (c < p.C) {
                 double ta = 0.0, tb = 0.0;
                 for (int r = 0; r < rpb; ++r) { ta += s1[(r * c4n + tid) * 4 + k]; tb += s2[(r * c4n + tid) * 4 + k]; }
-                p.part[(long)c * gridDim.x + blockIdx.x] = ta;                    // [2][C][rows]
-                p.part[((long)p.C + c) * gridDim.x + blockIdx.x] = tb;
+                p.part[(long)c * part_rows + part_row] = ta;                       // [2][C][rows]
+                p.part[((long)p.C + c) * part_rows + part_row] = tb;
             }
         }
     }
@@ -417,6 +510,26 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdParams 
     DR_PIN_ARGS(p.part, p.part_rows, p.C, p.M, p.gamma, p.bnc, p.coef, p.dbeta, p.dgamma);
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= p.C) return;
+    if (p.groups > 1) {                                   // micro-batch groups: coefficients per group, dbeta / dgamma summed in order
+        const float gam = p.gamma[c];
+        float db = p.dbeta[c], dg = p.dgamma[c];
+        for (int g = 0; g < p.groups; ++g) {
+            const float* bnc = p.bnc + (long)g * p.bnc_stride;
+            const float r = bnc[2 * p.C + c], d = bnc[3 * p.C + c], istd = bnc[p.C + c];
+            double sg, sgy;
+            fold_partials_wave(p.part, p.part_rows, p.C, c, g * p.rows_per_group, p.rows_per_group, sg, sgy);
+            if ((threadIdx.x & 63) == 0) {
+                float* coef = p.coef + (long)g * 3 * p.C;
+                coef[0 * p.C + c] = gam * r * istd;
+                coef[1 * p.C + c] = (float)(sg / (double)p.Mg);
+                coef[2 * p.C + c] = (float)(sgy / (double)p.Mg);
+                db = db + (float)sg;
+                dg = dg + (r * (float)sgy + d * (float)sg);
+            }
+        }
+        if ((threadIdx.x & 63) == 0) { p.dbeta[c] = db; p.dgamma[c] = dg; }
+        return;
+    }
     // everything the last lines read, before the fold (one round trip beside the fold's instead of one behind it)
     const float r = p.bnc[2 * p.C + c], d = p.bnc[3 * p.C + c], istd = p.bnc[p.C + c], gam = p.gamma[c];
     const float db0 = p.dbeta[c], dg0 = p.dgamma[c];
@@ -433,8 +546,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdParams 
 
 // MODE 0: coefficients from a bn_bwd_finalize_kernel launch; 1 (FUSE): fold the few partial rows here; 2: look-back hand-off
 template <int MODE>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) {
-    DR_PIN_ARGS(p.dout.p, p.dout.cs, p.dout.coff, p.raw, p.raw_cs, p.M, p.C, p.relu, p.scale, p.shift, p.bnc, p.coef, p.draw, p.dres.p, p.dres.cs, p.dres.coff, p.dres_acc, p.draw_bf16, p.part, p.part_rows);
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_in) {
+    DR_PIN_ARGS(p_in.dout.p, p_in.dout.cs, p_in.dout.coff, p_in.raw, p_in.raw_cs, p_in.M, p_in.C, p_in.relu, p_in.scale, p_in.shift, p_in.bnc, p_in.coef, p_in.draw, p_in.dres.p, p_in.dres.cs, p_in.dres.coff, p_in.dres_acc, p_in.draw_bf16, p_in.part, p_in.part_rows);
+    BnBwdParams p = p_in;
+    if (MODE == 0 && p.groups > 1) {                      // blockIdx.y = micro-batch group: its rows, its coefficients
+        const long g = blockIdx.y, r0 = g * p.Mg;
+        p.dout.p += r0 * p.dout.cs; p.raw += r0 * p.raw_cs;
+        if (p.draw_bf16) p.draw = reinterpret_cast<float*>(reinterpret_cast<__bf16*>(p.draw) + r0 * p.raw_cs);
+        else p.draw += r0 * p.raw_cs;
+        if (p.dres.p) p.dres.p += r0 * p.dres.cs;
+        p.scale += g * p.fold_stride; p.shift += g * p.fold_stride; p.bnc += g * p.bnc_stride; p.coef += g * 3 * p.C;
+        p.M = p.Mg;
+    }
     constexpr bool FUSE = MODE == 1;
     __shared__ float s_c[FUSE ? 3 : 1][FUSE ? 1024 : 1];
     const int nprod = MODE == 2 ? (p.C + 3) >> 2 : 0;          // [producers | streaming workgroups], see bn_train_apply_kernel
@@ -793,30 +916,35 @@ __global__ __launch_bounds__(256) void reg_loss_kernel(const float* param, const
     __syncthreads();
     if (threadIdx.x == 0) acc[(long)blockIdx.y * gridDim.x + blockIdx.x] = (double)sg.wd * 0.5 * (red[0] + red[1] + red[2] + red[3]);
 }
-__global__ __launch_bounds__(256) void reg_grad_kernel(const float* param, float* grad, const RegSeg* segs, int nseg) {
+// times: the micro-steps this sweep stands for (micro-batch groups: each of them carries the regulariser once)
+__global__ __launch_bounds__(256) void reg_grad_kernel(const float* param, float* grad, const RegSeg* segs, int nseg, float times) {
     for (int s = blockIdx.y; s < nseg; s += gridDim.y) {
         const RegSeg sg = segs[s];
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < sg.n; i += (long)gridDim.x * 256)
-            grad[sg.off + i] += sg.wd * param[sg.off + i];
+            grad[sg.off + i] += times * (sg.wd * param[sg.off + i]);
     }
 }
 // Sums the partial rows of the loss kernels in a fixed order (1168 same-address fp64 atomics cost 100 us here and made
 // the reported loss depend on their order).  loss_part = [3][n_loss] rows of loss_kernel, reg_part = n_reg partials.
+// Micro-batch groups: workgroup g writes out[4 g ..] from the pixel blocks of its group -- loss_part rows are [3][J][nblk] and a
+// group owns nblk / gridDim.x consecutive blocks of every joint's row (gridDim.x = 1: all of them, in index order as before).
 __global__ __launch_bounds__(256) void losses_out_kernel(const double* loss_part, int n_loss, const double* reg_part, int n_reg,
-                                                         float* out) {
+                                                         float* out, int nblk) {
     // one wave per loss term (the regulariser's ~9000 partials were a 146-deep chain of dependent loads on one wave: 38 us);
     // per wave: lane-strided loads, four independent accumulators, fixed shuffle tree -- the order never depends on timing
     const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
     const double* src = t < 3 ? loss_part + (long)t * n_loss : reg_part;
-    const int n = t < 3 ? n_loss : n_reg;
+    const int bpg = nblk / (int)gridDim.x, g0 = (int)blockIdx.x * bpg;                 // this group's blocks of each joint row
+    const int n = t < 3 ? (n_loss / nblk) * bpg : n_reg;
+    auto at = [&](int i) -> double { return t < 3 ? src[(long)(i / bpg) * nblk + g0 + i % bpg] : src[i]; };
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int i = lane;
-    for (; i + 3 * 64 < n; i += 4 * 64) { a0 += src[i]; a1 += src[i + 64]; a2 += src[i + 128]; a3 += src[i + 192]; }
-    for (; i < n; i += 64) a0 += src[i];
+    for (; i + 3 * 64 < n; i += 4 * 64) { a0 += at(i); a1 += at(i + 64); a2 += at(i + 128); a3 += at(i + 192); }
+    for (; i < n; i += 64) a0 += at(i);
     double a = (a0 + a1) + (a2 + a3);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
-    if (lane == 0) out[t] = (float)a;
+    if (lane == 0) out[4 * blockIdx.x + t] = (float)a;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -65,6 +65,7 @@ class Engine:
         self.map_hw = in_hw // 4
         self.max_batch = max_batch
         self.training = training
+        self.groups = 1
 
     # ---- plumbing ---------------------------------------------------------------------------
     def _stream(self):
@@ -138,7 +139,9 @@ class Engine:
                     C.c_uint64(seed), self._stream())
 
     def loss(self, dm_norm, pose_mm, cfg, com) -> torch.Tensor:
-        out = self.new(4)
+        """The four loss terms of the last ``forward_train``: a tensor of 4, or ``[groups, 4]`` (one row per micro-batch) after
+        ``set_groups(G > 1)``."""
+        out = self.new(4) if self.groups == 1 else self.new(self.groups, 4)
         self.h.call('dr_loss', dm_norm.shape[0], _p(dm_norm), _p(_f32(pose_mm)), _p(_f32(cfg)), _p(_f32(com)), _p(out),
                     self._stream())
         return out
@@ -153,6 +156,19 @@ class Engine:
         """Micro-steps in flight (``dr_set_pipeline``): 1 or 2.  Going to 1 finishes what is in flight and folds the gradients."""
         self.h.call('dr_set_pipeline', int(depth))
         self.pipeline = int(depth)
+
+    def set_groups(self, groups: int):
+        """Micro-batch groups (``dr_set_groups``): the next ``forward_train`` / ``loss`` / ``backward`` take ``groups`` consecutive
+        micro-batches of one accumulation window at once (per-micro-batch BatchReNorm statistics and state chain, summed
+        gradient); 1 restores one micro-batch per call."""
+        if int(groups) != self.groups:
+            self.h.call('dr_set_groups', int(groups))
+            self.groups = int(groups)
+
+    def groups_supported(self, micro_batch: int, groups: int) -> bool:
+        """Can ``groups`` micro-batches of ``micro_batch`` crops run as one pass on this engine?  (``dr_set_groups``: at most 8
+        groups, whole 32-row tiles per micro-batch in the 2x2 layers = a multiple of 8 crops, and the buffers to hold them.)"""
+        return (self.training and 1 <= groups <= 8 and micro_batch % 8 == 0 and micro_batch * groups <= self.max_batch)
 
     def sync_grads(self):
         """Order the current stream behind every micro-step in flight and make ``flat_view('grad')`` the sum of all slots'

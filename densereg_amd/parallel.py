@@ -100,6 +100,26 @@ class DataParallelTrainer:
             self.optimizer_step(dm_norm.shape[0])
         return losses
 
+    def window_step(self, dm_norm, pose_mm, cfg, com, seed: int = 0, dropout_mode: int = 2, keep_mask=None):
+        """A whole accumulation window at once: the tensors hold ``sub_batch`` consecutive micro-batches, the engine runs them as
+        micro-batch groups in ONE pass of launches (``Engine.set_groups``: per-micro-batch BatchReNorm statistics, the state
+        chained in order, the gradient sum) and the optimizer step follows -- what ``sub_batch`` calls of ``micro_step`` do, with
+        ``sub_batch`` times the rows per kernel launch.  Returns the loss terms ``[sub_batch, 4]`` (device)."""
+        eng, G = self.eng, self.sub_batch
+        B = dm_norm.shape[0]
+        if B % G:
+            raise ValueError('window_step: %d crops are not %d micro-batches' % (B, G))
+        eng.set_groups(G)
+        try:
+            eng.forward_train(dm_norm, dropout_mode, keep_mask, rank_seed(seed, self.rank, self.world))
+            losses = eng.loss(dm_norm, pose_mm, cfg, com)
+            eng.backward(B)
+        finally:
+            eng.set_groups(1)
+        self.micro += G
+        self.optimizer_step(B // G)
+        return losses.reshape(G, 4)
+
     def optimizer_step(self, batch_size: int):
         """``sess.run(train_op)`` (:150) then ``reset_op`` (:144)."""
         self.reduce_gradients()

@@ -153,6 +153,17 @@ int dr_zero_grad(dr_handle* h, dr_stream stream);                       /* reset
  * dr_sync_grads / dr_apply_adam: results are deterministic, and equal depth 1's up to the rounding of that one addition.
  * Entry points that read the handle's buffers from the host (dr_read_param, dr_read_activation, ...) drain the pipeline first. */
 int dr_set_pipeline(dr_handle* h, int depth);
+/* Micro-batch groups (training handles; default 1, at most 8).  With groups = G the next dr_forward_train / dr_loss /
+ * dr_backward calls take the G micro-batches of one accumulation window at once: their B crops (and the rows of pose / cfg /
+ * com / a keep mask) are G consecutive micro-batches of B/G crops, and one pass of launches does what G micro-steps of the
+ * reference do one after the other (train_single_gpu.py:138-150) -- BatchReNorm statistics, r / d and the clip schedule per
+ * micro-batch; the moving statistics and the zero-debias accumulators chained through the micro-batches in order (micro-batch
+ * g normalises with what g-1 left, slim/ops.py:134-162); the gradient sum and G times the regulariser added to the accumulator.
+ * losses_dev then receives G rows of four, one per micro-batch.  Same numbers as G separate micro-steps up to the rounding
+ * of sums taken in another order (the kernels see 4x-8x the rows per launch: that is the point).  DR_DROPOUT_RNG draws one
+ * mask over all B crops from `seed`.  Requires B % G == 0 and B/G a multiple of 8 crops (whole 128-row tiles per micro-batch
+ * in the smallest, 4x4, layers); DR_E_UNSUPPORTED otherwise. */
+int dr_set_groups(dr_handle* h, int groups);
 /* Orders `stream` behind every micro-step in flight and folds all sets' accumulated gradients into the buffer dr_flat_grad
  * names (call it before an all-reduce of that buffer: train_multi_gpu.py:16-39).  A no-op at depth 1. */
 int dr_sync_grads(dr_handle* h, dr_stream stream);

@@ -1,0 +1,107 @@
+"""Micro-batch groups (``dr_set_groups``): the G micro-steps of one accumulation window as ONE pass of launches, against the
+same G micro-steps run one after the other (the reference's loop, train_single_gpu.py:138-150).  Same arithmetic per
+micro-batch -- statistics, r / d, the clip schedule, the moving-statistics chain -- with sums taken over other tile shapes:
+losses and BatchReNorm state agree to fp32 rounding, the accumulated gradient to the bar of the gradient tests."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.common import _flat_rw
+
+BACKENDS = [pytest.param('emu'), pytest.param('gpu', marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def be(request):
+    return request.getfixturevalue(request.param)
+
+
+def _case(be, G, Bg):
+    from densereg_amd.data.synthetic import make_crops
+    from oracle import net, pose
+    from oracle.graph import NetConfig
+    S, F, J = (1, 8, 2) if be.name == 'emu' else (2, 64, 5)
+    cfg = NetConfig(S, F, J)
+    dm, poses, cfgs, coms, _ = make_crops(G * Bg, 'icvl', seed=77)
+    ndm = pose.norm_dm(dm, coms)
+    params = net.make_test_params(cfg, ndm[:2], seed=5)
+    return cfg, params, (ndm, np.ascontiguousarray(poses[:, :3 * J]), cfgs, coms)
+
+
+def _run(be, cfg, params, data, G, Bg, fused, windows=1):
+    """`windows` accumulation windows of G micro-batches (the same data each time: the state chain is what differs); returns
+    (losses [windows*G][4], accumulated gradient of the last window, parameters incl. BatchReNorm state)."""
+    B = G * Bg
+    h = be.handle(cfg, B, training=True)
+    h.load_params(params)
+    h.call('dr_finalize_params', be.stream)
+    bufs = [be.dev(np.ascontiguousarray(a)) for a in data]
+    losses = []
+    for w in range(windows):
+        h.call('dr_zero_grad', be.stream)
+        if fused:
+            h.call('dr_set_groups', G)
+            d_lo = be.empty((G, 4))
+            h.call('dr_forward_train', B, be.ptr(bufs[0]), 0, None, C.c_uint64(9), be.stream)
+            h.call('dr_loss', B, be.ptr(bufs[0]), be.ptr(bufs[1]), be.ptr(bufs[2]), be.ptr(bufs[3]), be.ptr(d_lo), be.stream)
+            h.call('dr_backward', B, be.stream)
+            be.sync()
+            losses.extend(be.host(d_lo).reshape(G, 4).copy())
+        else:
+            for g in range(G):
+                sl = [be.dev(np.ascontiguousarray(a[g * Bg:(g + 1) * Bg])) for a in data]
+                d_lo = be.empty((4,))
+                h.call('dr_forward_train', Bg, be.ptr(sl[0]), 0, None, C.c_uint64(9), be.stream)
+                h.call('dr_loss', Bg, be.ptr(sl[0]), be.ptr(sl[1]), be.ptr(sl[2]), be.ptr(sl[3]), be.ptr(d_lo), be.stream)
+                h.call('dr_backward', Bg, be.stream)
+                be.sync()
+                losses.append(be.host(d_lo).copy())
+    addr, n = h.flat('grad')
+    grad = _flat_rw(be, addr, n)[0]().copy()
+    out = np.array(losses), grad, h.read_params()
+    h.close()
+    return out
+
+
+def _compare(lo_s, g_s, p_s, lo_f, g_f, p_f, params):
+    assert np.isfinite(lo_f).all() and np.isfinite(g_f).all()
+    np.testing.assert_allclose(lo_f, lo_s, rtol=2e-5)
+    for k in p_s:
+        if 'moving' in k:
+            np.testing.assert_allclose(p_f[k], p_s[k], rtol=2e-5, atol=1e-6 * max(1.0, float(np.abs(p_s[k]).max())), err_msg=k)
+        elif k.endswith(('r_max', 'd_max', 'curr_t')):
+            np.testing.assert_array_equal(p_f[k], p_s[k], err_msg=k)
+    # the moving statistics moved (the chain is really G updates long)
+    moved = [k for k in p_s if 'moving_mean' in k and np.abs(p_s[k] - params[k]).max() > 0]
+    assert len(moved) > 0
+    scale = float(np.abs(g_s).max())
+    err = np.abs(g_f - g_s)
+    assert err.max() <= 2e-3 * scale, (err.max(), scale)
+    assert np.median(err) <= 1e-5 * scale
+
+
+def test_groups_match_sequential_micro_steps(be):
+    G, Bg = (2, 8) if be.name == 'emu' else (3, 8)
+    cfg, params, data = _case(be, G, Bg)
+    windows = 1 if be.name == 'emu' else 2
+    lo_s, g_s, p_s = _run(be, cfg, params, data, G, Bg, fused=False, windows=windows)
+    lo_f, g_f, p_f = _run(be, cfg, params, data, G, Bg, fused=True, windows=windows)
+    assert lo_f.shape == (windows * G, 4)
+    # the micro-batches differ, and so do their losses: the rows are really per group
+    assert np.abs(lo_f[0, :3] - lo_f[1, :3]).max() > 0
+    _compare(lo_s, g_s, p_s, lo_f, g_f, p_f, params)
+
+
+def test_groups_reject_what_the_tiles_cannot_cut(be):
+    from oracle.graph import NetConfig
+    cfg = NetConfig(1, 8, 2)
+    h = be.handle(cfg, 6, training=True)
+    from densereg_amd._lib import DenseRegError
+    with pytest.raises(DenseRegError):
+        h.call('dr_set_groups', 9)
+    h.call('dr_set_groups', 2)
+    dm = be.dev(np.zeros((6, 128, 128), np.float32))
+    with pytest.raises(DenseRegError):          # 5 crops are not two equal groups
+        h.call('dr_forward_train', 5, be.ptr(dm), 0, None, C.c_uint64(0), be.stream)
+    h.close()

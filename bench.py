@@ -206,10 +206,11 @@ def main():
     # the window fits comfortably: up to 262 144 pixels per full-resolution layer (5 x 40 crops at 32x32 maps: 204 800)
     G = 1
     if mode == 'train':
-        G = args.groups if args.groups >= 1 else (args.sub_batch if (2 <= args.sub_batch <= 8 and B % 8 == 0 and
-                                                                     B * args.sub_batch * (HW // 4) ** 2 <= 262144) else 1)
-        if G > 1 and (G != args.sub_batch or B % 8):
-            raise SystemExit('bench.py: --groups %d needs sub_batch == groups and a batch that is a multiple of 8' % G)
+        from densereg_amd.parallel import window_groups
+        try:
+            G = window_groups(B, args.sub_batch, HW, args.groups)
+        except ValueError as e:
+            raise SystemExit('bench.py: %s' % e)
     eng = Engine(S, F, J, HW, 3, B * G, local, training=(mode == 'train'))
     bf16 = args.precision == 'bf16'
     if bf16:

@@ -35,7 +35,7 @@ from ..data import preprocess
 from ..data.evaluation import Evaluation
 from ..data.synthetic import DATASETS, make_crops
 from ..network import um_v1
-from ..parallel import DataParallelTrainer, check_world, decay_steps, per_rank_batch
+from ..parallel import DataParallelTrainer, check_world, decay_steps, per_rank_batch, window_groups
 
 
 class SyntheticDataset:
@@ -76,7 +76,9 @@ class JointDetectionModel(object):
         if F.is_aug:
             self._model_desc += '_daug'
         self.device = torch.device('cuda', device)
-        self.engine = um_v1.get_engine(self._jnt_num, self._input_height, self._rank_batch, device, bool(F.is_train))
+        # training: the micro-steps of an accumulation window as one pass of launches where that pays (parallel.window_groups)
+        self._groups = window_groups(self._rank_batch, F.sub_batch, self._input_height, getattr(F, 'groups', -1)) if F.is_train else 1
+        self.engine = um_v1.get_engine(self._jnt_num, self._input_height, self._rank_batch * self._groups, device, bool(F.is_train))
 
     # ---- hyper-parameters (:159-182) -----------------------------------------------------------
     @property
@@ -99,6 +101,11 @@ class JointDetectionModel(object):
     def rank_batch(self):
         """crops per micro-step on THIS rank: the global --batch_size split over the ranks"""
         return self._rank_batch
+
+    @property
+    def window_groups(self):
+        """micro-steps per pass of launches (1, or --sub_batch: the whole accumulation window)"""
+        return self._groups
 
     @property
     def name(self):
@@ -160,17 +167,28 @@ def train(model: JointDetectionModel, dist=None, log=sys.stdout):
     for step in range(start_step, max_steps):
         start = time.time()
         ave_loss = 0.0
+        window = []
         for _ in range(F.sub_batch):
             dm, poses, cfgs, coms, _n = model._dataset.batch(model.rank_batch, micro)
             d_dm, d_pose, d_cfg, d_com = model._t(dm), model._t(poses), model._t(cfgs), model._t(coms)
             if F.is_aug:                                                    # hourglass_um_crop_tiny.py:332-333
                 d_dm, d_pose = preprocess.data_aug(d_dm, d_pose, d_cfg, d_com, generator=aug_rng)
             normed = model.engine.norm_dm(d_dm, d_com)
+            if model.window_groups > 1:                                     # the window runs as one pass once it is complete
+                window.append((normed, d_pose, d_cfg, d_com))
+                micro += 1
+                continue
             losses = trainer.micro_step(normed, d_pose, d_cfg, d_com, seed=micro)
             loss_value = float(losses.sum().item())
             assert not np.isnan(loss_value), 'Model diverged with loss = NaN'          # :147
             ave_loss += loss_value
             micro += 1
+        if window:
+            parts = [torch.cat([w[k] for w in window]) for k in range(4)]
+            losses = trainer.window_step(*parts, seed=micro - F.sub_batch)             # [sub_batch, 4]: one row per micro-step
+            for loss_value in losses.sum(dim=1).tolist():
+                assert not np.isnan(loss_value), 'Model diverged with loss = NaN'      # :147
+                ave_loss += loss_value
         ave_loss /= F.sub_batch
         duration = time.time() - start
         if log and step % 5 == 0:

@@ -56,6 +56,28 @@ def learning_rate(step: int, dataset: str, batch_size: int, sub_batch: int) -> f
     return INIT_LR * LR_DECAY ** math.floor(step / decay_steps(dataset, batch_size, sub_batch))
 
 
+def window_groups(micro_batch: int, sub_batch: int, in_hw: int, override=None) -> int:
+    """How many micro-steps of an accumulation window run as ONE pass of launches (``dr_set_groups``): ``sub_batch`` (the whole
+    window) or 1.  The pass needs 2..8 micro-batches of a multiple of 8 crops (include/densereg.h) and buffers for the whole
+    window; by default it is used up to 262 144 pixels per full-resolution layer and window (5 x 40 crops on 32x32 maps: 204 800
+    -- measured on MI355X: 2250 -> 2511 crops/s fp32, 3944 -> 4827 bf16; a 256x256-crop window would be 819 200 pixels and
+    4x the activation memory for kernels that already run many rounds of workgroups).  ``override`` (``--groups`` /
+    ``DR_GROUPS``): 0 or 1 = one micro-step per pass, ``sub_batch`` = the whole window or an error if it cannot be."""
+    if override is not None and override < 0:
+        override = None
+    if override is None and os.environ.get('DR_GROUPS') not in (None, ''):
+        override = int(os.environ['DR_GROUPS'])
+    ok = 2 <= sub_batch <= 8 and micro_batch % 8 == 0
+    if override is not None and override >= 0:
+        if override <= 1:
+            return 1
+        if not ok or override != sub_batch:
+            raise ValueError('groups=%d: needs groups == sub_batch (%d) in 2..8 and micro-batches of a multiple of 8 crops (%d)'
+                             % (override, sub_batch, micro_batch))
+        return sub_batch
+    return sub_batch if ok and micro_batch * sub_batch * (in_hw // 4) ** 2 <= 262144 else 1
+
+
 class DataParallelTrainer:
     def __init__(self, engine, dataset: str = 'nyu', sub_batch: int = 5, dist=None, all_reduce=None):
         """``micro_step`` takes this rank's share of the minibatch; the learning-rate staircase counts optimizer steps

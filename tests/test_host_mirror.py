@@ -148,6 +148,42 @@ def test_synthetic_dataset_constants():
     assert 0.25 < (dm > 0).mean() < 0.6 and np.all(cfg[:, 4:] == 128)
 
 
+def test_accumulation_window_as_one_pass_policy_and_bookkeeping():
+    """parallel.window_groups picks the pass size; DataParallelTrainer.window_step does the bookkeeping of `sub_batch` micro-steps
+    and the optimizer step around ONE forward / loss / backward of the engine in groups mode."""
+    from densereg_amd.parallel import DataParallelTrainer, window_groups
+    assert window_groups(40, 5, 128) == 5                    # BASELINE configs 2-4: 40 crops x 5 micro-steps on 32x32 maps
+    assert window_groups(40, 5, 256) == 1                    # config 5: 64x64 maps, the window would be 819 200 pixels per layer
+    assert window_groups(40, 1, 128) == 1 and window_groups(40, 9, 128) == 1 and window_groups(4, 2, 128) == 1
+    assert window_groups(40, 5, 128, override=0) == 1 and window_groups(40, 5, 256, override=5) == 5
+    with pytest.raises(ValueError):
+        window_groups(4, 2, 128, override=2)                 # 4 crops per micro-batch: the 2x2 layers cannot be cut into tiles
+    with pytest.raises(ValueError):
+        window_groups(40, 5, 128, override=3)
+    calls = []
+
+    class _T:
+        def __init__(self, n): self.shape = (n,)
+        def reshape(self, *s): calls.append(('reshape', s)); return self
+
+    class _Eng:
+        pipeline = 1
+        def flat_view(self, which): return None
+        def zero_grad(self): calls.append('zero')
+        def set_groups(self, g): calls.append(('groups', g))
+        def forward_train(self, dm, mode, mask, seed): calls.append(('fwd', dm.shape[0], seed))
+        def loss(self, dm, pose, cfg, com): calls.append('loss'); return _T(20)
+        def backward(self, B): calls.append(('bwd', B))
+        def apply_adam(self, lr, div, step, clip): calls.append(('adam', div, step))
+    tr = DataParallelTrainer(_Eng(), dataset='nyu', sub_batch=5)
+    calls.clear()
+    tr.window_step(_T(200), None, None, None, seed=10)
+    assert calls == [('groups', 5), ('fwd', 200, 10), 'loss', ('bwd', 200), ('groups', 1), ('adam', 5.0, 1), 'zero', ('reshape', (5, 4))]
+    assert tr.micro == 5 and tr.global_step == 1
+    with pytest.raises(ValueError):
+        tr.window_step(_T(201), None, None, None)
+
+
 @pytest.mark.gpu
 def test_cli_test_and_train_drivers_on_gpu(gpu, tmp_path, monkeypatch):
     from densereg_amd import flags
@@ -172,8 +208,19 @@ def test_cli_test_and_train_drivers_on_gpu(gpu, tmp_path, monkeypatch):
     before = eng.read_params()
     model, trainer = M.run_train(ds, None)
     after = eng.read_params()
-    assert trainer.global_step == 2
+    assert trainer.global_step == 2 and model.window_groups == 1
     assert any(np.abs(after[k] - before[k]).max() > 0 for k in before if k.endswith('weights'))
+    # ... and with micro-batches the engine can run as groups: each accumulation window is one pass (parallel.window_groups)
+    flags.parse(['--dataset', 'nyu', '--num_stack', '1', '--fea_num', '64', '--is_train', 'True', '--batch_size', '8',
+                 '--sub_batch', '2', '--max_steps', '2'])
+    eng = um_v1.get_engine(14, 128, 16, 0, True)
+    eng.load_params(M._random_params(eng))
+    before = eng.read_params()
+    model, trainer = M.run_train(ds, None)
+    after = eng.read_params()
+    assert model.window_groups == 2 and model.engine is eng and trainer.global_step == 2 and trainer.micro == 4
+    assert any(np.abs(after[k] - before[k]).max() > 0 for k in before if k.endswith('weights'))
+    assert all(np.isfinite(v).all() for v in after.values())
     flags.parse([])
 
 

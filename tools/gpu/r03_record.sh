@@ -9,7 +9,8 @@ timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $G/r03_smoke.lo
 timeout 400 python bench.py --detail $G/r03_detail_train.md > $G/r03_bench_train.json 2> $G/r03_bench_train.err; echo "bench rc=$?" >> $G/r03_bench_train.err
 timeout 300 python bench.py --mode infer --detail $G/r03_detail_infer.md > $G/r03_bench_infer.json 2> $G/r03_bench_infer.err
 Q="--no-cpu-baseline --steps 40 --warmup 10"
-DR_PIPELINE=1 timeout 200 python bench.py $Q --no-forward-vote --no-profile > $G/r03_bench_train_depth1.json 2> $G/r03_bench_train_depth1.err
+timeout 200 python bench.py $Q --groups 1 --no-forward-vote --no-profile > $G/r03_bench_train_g1.json 2> $G/r03_bench_train_g1.err      # one micro-step per pass, two in flight
+DR_PIPELINE=1 timeout 200 python bench.py $Q --groups 1 --no-forward-vote --no-profile > $G/r03_bench_train_g1_depth1.json 2> $G/r03_bench_train_g1_depth1.err
 timeout 200 python bench.py --dataset msra $Q > $G/r03_bench_msra.json 2> $G/r03_bench_msra.err
 timeout 200 python bench.py --precision bf16 $Q > $G/r03_bench_train_bf16.json 2> $G/r03_bench_train_bf16.err
 C5="--num_stack 4 --num_fea 256 --in_hw 256 --dataset nyu --no-cpu-baseline --steps 20 --warmup 5"
@@ -25,12 +26,12 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/$G/prof_train -o train -- pyt
 DR_PIPELINE=1 DR_WGRAD_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$G/prof_train_inline -o train -- python $R/bench.py --steps 10 --warmup 5 $P > $R/$G/rocprof_train_inline.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$G/prof_infer -o infer -- python $R/bench.py --mode infer --replicas 1 --steps 10 --warmup 5 $P > $R/$G/rocprof_infer.log 2>&1
 cd $R
-bash tools/gpu/pmc_passes.sh train
+PMC_STEPS=5 PMC_WARMUP=5 bash tools/gpu/pmc_passes.sh train          # whole windows: the launches bench.py's roofline leg times
 bash tools/gpu/pmc_passes.sh infer --mode infer --replicas 1
-bash tools/gpu/pmc_passes.sh train_bf16 --precision bf16
+PMC_STEPS=5 PMC_WARMUP=5 bash tools/gpu/pmc_passes.sh train_bf16 --precision bf16
 bash tools/gpu/pmc_passes.sh train_bf16_s4f256hw256 --num_stack 4 --num_fea 256 --in_hw 256 --dataset nyu --precision bf16
 tail -6 $G/r03_pytest_gpu.log; tail -2 $G/r03_smoke.log; cat $G/test_branches.jsonl
-for f in train infer train_depth1 msra train_bf16 c5_bf16 c5_f32 torchrun allreduce; do python - <<PY
+for f in train infer train_g1 train_g1_depth1 msra train_bf16 c5_bf16 c5_f32 torchrun allreduce; do python - <<PY
 import json
 try:
     d=json.load(open('$G/r03_bench_$f.json')); fv=d.get('forward_vote') or {}

@@ -5,7 +5,7 @@ set -e
 R=${1:-r03}
 cd "$(dirname "$0")/.."
 G=gpurun_out
-python tools/rocpd_summary.py $G/prof_train/train_results.db "bench.py --steps 10 --warmup 5 (train mode, round ${R#r}; default executor: two micro-steps in flight on two streams + the side streams of the full-resolution weight gradients, so kernels overlap and the column sums exceed the step time)" > profiles/${R}_train_kernel_stats.md
+python tools/rocpd_summary.py $G/prof_train/train_results.db "bench.py --steps 10 --warmup 5 (train mode, round ${R#r}; default executor: the five micro-steps of an accumulation window as one pass of launches + the side stream of the full-resolution weight gradients, whose kernels overlap the main stream's)" > profiles/${R}_train_kernel_stats.md
 [ -f $G/prof_train_inline/train_results.db ] && python tools/rocpd_summary.py $G/prof_train_inline/train_results.db "DR_PIPELINE=1 DR_WGRAD_STREAM=0 bench.py --steps 10 --warmup 5 (train mode, round ${R#r}; everything on the caller's stream: what bench.py's roofline leg times)" > profiles/${R}_train_kernel_stats_inline.md
 python tools/rocpd_summary.py $G/prof_infer/infer_results.db "bench.py --mode infer --replicas 1 --steps 10 --warmup 5 (round ${R#r})" > profiles/${R}_infer_kernel_stats.md
 for m in train infer train_bf16 train_bf16_s4f256hw256; do
@@ -14,7 +14,7 @@ for m in train infer train_bf16 train_bf16_s4f256hw256; do
     python tools/rocpd_pmc.py $G/pmc_${m}_fetch/fetch_results.db $G/pmc_${m}_write/write_results.db --json $m profiles/pmc_traffic.json $G/pmc_${m}_stamp.json
   fi
 done
-for n in train infer msra c5_bf16 c5_f32 train_bf16 torchrun allreduce train_depth1; do
+for n in train infer msra c5_bf16 c5_f32 train_bf16 torchrun allreduce train_g1 train_g1_depth1; do
   [ -s $G/${R}_bench_$n.json ] && cp $G/${R}_bench_$n.json profiles/${R}_bench_$n.json
 done
 cp $G/${R}_detail_train.md profiles/${R}_train_per_layer.md

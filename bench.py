@@ -62,7 +62,9 @@ def parse():
     ap.add_argument('--groups', type=int, default=int(os.environ.get('DR_BENCH_GROUPS', '-1')),
                     help='train mode: micro-steps of an accumulation window run as ONE pass of launches (dr_set_groups). '
                          '-1 = auto (sub_batch where the engine supports it and the window fits), 1 = one micro-step per pass')
-    ap.add_argument('--replicas', type=int, default=3,
+    ap.add_argument('--merge', type=int, default=int(os.environ.get('DR_BENCH_MERGE', '5')),
+                    help='forward(eval)+vote: consecutive submitted batches run as one launch of this many batches (ReplicaPool merge)')
+    ap.add_argument('--replicas', type=int, default=2,
                     help='forward(eval)+vote: inference replicas per GPU, consecutive batches alternate between them '
                          '(densereg_amd/serving.py; 1 = one engine, one stream)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -211,7 +213,8 @@ def main():
             G = window_groups(B, args.sub_batch, HW, args.groups)
         except ValueError as e:
             raise SystemExit('bench.py: %s' % e)
-    eng = Engine(S, F, J, HW, 3, B * G, local, training=(mode == 'train'))
+    MG = max(1, args.merge) if mode == 'infer' else 1       # forward(eval)+vote: batches per launch (ReplicaPool merge)
+    eng = Engine(S, F, J, HW, 3, B * max(G, MG), local, training=(mode == 'train'))
     bf16 = args.precision == 'bf16'
     if bf16:
         eng.set_precision('bf16')
@@ -242,23 +245,29 @@ def main():
         wdm, wposes, wcfgs, wcoms, _ = make_crops(B * G, dataset, seed=20240, rank=rank, hw=HW)
         w_pose, w_cfg, w_com = t(wposes), t(wcfgs), t(wcoms)
         w_dm = eng.norm_dm(t(wdm), w_com)
+    if MG > 1:                                               # what a replica launches: MG batches side by side (the roofline leg times this)
+        m_dm, m_cfg, m_com = (torch.cat([x] * MG) for x in (d_dm, d_cfg, d_com))
+        m_xyz = eng.new(B * MG, 3 * J)
     pending = [0]                                            # micro-steps handed in since the last window / flush
+    live_pools = []
 
     # forward(eval)+vote throughput: `--replicas` engines with the same weights, each on its own stream, take the batches in turn
     # (north-star: inference = replicas; the single-engine figure is reported next to it)
     def make_pool(Jn):
         from densereg_amd.serving import ReplicaPool
-        pool = ReplicaPool(args.replicas, S, F, Jn, HW, 3, B, local)
+        pool = ReplicaPool(args.replicas, S, F, Jn, HW, 3, B, local, merge=args.merge)
         if bf16:
             pool.set_precision('bf16')
         pool.load_params(random_params(pool))
-        return pool, [pool.engines[0].new(B, 3 * Jn) for _ in range(args.replicas)]
-    pool, pool_out = make_pool(J) if (mode == 'infer' and args.replicas > 1) else (None, None)
+        return pool, [pool.engines[0].new(B, 3 * Jn) for _ in range(args.replicas * args.merge)]
+    pool, pool_out = make_pool(J) if (mode == 'infer' and args.replicas * args.merge > 1) else (None, None)
+    if pool is not None:
+        live_pools.append(pool)
 
     def step(i):
         if mode == 'infer':
             if pool is not None:
-                pool.submit(d_dm, d_cfg, d_com, out=pool_out[i % args.replicas])
+                pool.submit(d_dm, d_cfg, d_com, out=pool_out[i % len(pool_out)])
             else:
                 eng.infer(d_dm, d_cfg, d_com, out=xyz)
         elif G > 1:                                          # every G-th micro-step launches the window they form
@@ -274,6 +283,8 @@ def main():
         for _ in range(pending[0]):
             trainer.micro_step(d_dm, d_pose, d_cfg, d_com, seed=0)
         pending[0] = 0
+        for p in live_pools:                                   # a merged group still filling: launched, so exactly K batches are timed
+            p.flush()
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -305,6 +316,7 @@ def main():
         sdt = timed(lambda i: eng.infer(d_dm, d_cfg, d_com, out=xyz))
         single = {'value': B * world * args.steps / sdt, 'ms_per_step': sdt / args.steps * 1e3}
         pool.close()
+        live_pools.remove(pool)
         pool = None
 
     # ---- roofline leg: separate profiled pass (events around every op), same workload ------------
@@ -313,12 +325,16 @@ def main():
         eng.h.profile(True)
         nprof = max(2, min(5, args.steps))                     # profiled passes (training with groups: whole windows)
         for i in range(nprof * G):
-            step(1000 + i)
+            if MG > 1:
+                eng.infer(m_dm, m_cfg, m_com, out=m_xyz)       # a merged launch, as the replicas run it
+            else:
+                step(1000 + i)
         if args.detail and rank == 0:
             rows = sorted(eng.h.profile_detail(), key=lambda r: -r['total_ms'])
             tot = sum(r['total_ms'] for r in rows)
             with open(args.detail, 'w') as f:
-                f.write('# per-op timing (HIP events), %s mode, B=%d, %d profiled steps\n\n' % (mode, B, nprof))
+                f.write('# per-op timing (HIP events), %s mode, %d crops per pass of launches (%d x B=%d), %d profiled passes\n\n'
+                        % (mode, B * max(G, MG), max(G, MG), B, nprof))
                 f.write('| op | launches/step | us/launch | ms/step | % | TFLOP/s | GB/s (algorithmic) |\n|---|---:|---:|---:|---:|---:|---:|\n')
                 for r in rows:
                     ms = r['total_ms'] / nprof
@@ -337,7 +353,7 @@ def main():
             roof = {'kernel': dom['name'], 'bound': 'mfma', 'achieved': ach, 'peak': peak,
                     'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic, 'traffic_provenance': traffic_prov,
                     'launches_per_step': dom['launches'] / nprof, 'avg_launch_us': dom['total_ms'] * 1e3 / dom['launches'],
-                    'micro_steps_per_profiled_step': G,
+                    'micro_steps_per_profiled_step': G, 'batches_per_profiled_step': MG,
                     'algorithmic_gflop_per_launch': dom['flops'] / dom['launches'] / 1e9,
                     'share_of_step_time': dom['total_ms'] / max(sum(s['total_ms'] for s in stats), 1e-9),
                     # the runner-up family, same accounting (training: the forward/dgrad tile and the weight gradients trade places)
@@ -366,16 +382,18 @@ def main():
         i_xyz = ieng.new(B, 3 * Ji)
         idt1 = timed(lambda i: ieng.infer(i_dm, i_cfg, i_com, out=i_xyz))
         idt = idt1
-        if args.replicas > 1:
+        if args.replicas * args.merge > 1:
             ipool, iout = make_pool(Ji)
-            idt = timed(lambda i: ipool.submit(i_dm, i_cfg, i_com, out=iout[i % args.replicas]))
+            live_pools.append(ipool)
+            idt = timed(lambda i: ipool.submit(i_dm, i_cfg, i_com, out=iout[i % len(iout)]))
+            live_pools.remove(ipool)
             ipool.close()
         fwd_vote = {'metric': 'depth-crops/sec fwd(eval)+vote, %d-stack fea=%d @%dx%d' % (S, F, HW, HW),
                     'value': B * world * args.steps / idt, 'unit': 'crops/s', 'ms_per_step': idt / args.steps * 1e3,
                     'steps': args.steps, 'warmup': args.warmup,
                     'workload': 'ICVL S=%d F=%d J=%d B=%d/GPU %dx%d forward(eval) + vote -> xyz mm, %d GPU(s) x %d replica(s) per GPU '
-                                '(batches alternate between the replicas, each on its own stream)' % (S, F, Ji, B, HW, HW, world, args.replicas),
-                    'replicas_per_gpu': args.replicas,
+                                '(each on its own stream; a replica runs %d consecutive batches as one launch)' % (S, F, Ji, B, HW, HW, world, args.replicas, args.merge),
+                    'replicas_per_gpu': args.replicas, 'batches_per_launch': args.merge,
                     'single_replica': {'value': B * world * args.steps / idt1, 'ms_per_step': idt1 / args.steps * 1e3},
                     'conv_gflop_per_crop_fwd': ieng.conv_flops_per_crop() / 1e9}
         ieng.close()
@@ -408,7 +426,8 @@ def main():
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
                        'micro_steps_in_flight': eng_pipeline if mode == 'train' else None,
                        'micro_steps_per_pass': G if mode == 'train' else None,
-                       'replicas_per_gpu': args.replicas if mode == 'infer' else None, 'single_replica': single,
+                       'replicas_per_gpu': args.replicas if mode == 'infer' else None,
+                       'batches_per_launch': args.merge if mode == 'infer' else None, 'single_replica': single,
                        'world_size': dist.get_world_size() if dist is not None else 1, 'rccl_version': rccl,
                        'conv_gflop_per_crop_fwd': eng_flops / 1e9},
             'roofline': roof, 'cpu_baseline': cpu, 'forward_vote': fwd_vote,

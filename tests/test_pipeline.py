@@ -231,3 +231,48 @@ def test_inference_replicas_equal_one_engine(gpu):
     np.testing.assert_array_equal(xyz.cpu().numpy(), want[-1].cpu().numpy())
     pool.close()
     eng.close()
+
+
+@pytest.mark.gpu
+def test_inference_replicas_merging_batches_match_one_engine(gpu):
+    """ReplicaPool(merge=3): consecutive batches run as one launch of three times the rows -- per crop the same result as one
+    engine taking the batches one by one (other tile shapes may sum K in another order: a few ulp on the maps, micrometres on the
+    joints), in submission order, with ragged batches, caller-provided outputs, a group cut short by ``wait`` and by ``flush``."""
+    import torch
+    from densereg_amd.data.synthetic import make_crops
+    from densereg_amd.engine import Engine
+    from densereg_amd.serving import ReplicaPool
+    from oracle import net
+    from oracle.graph import NetConfig
+    S, F, J, B = 1, 32, 16, 8
+    params = net.init_params(NetConfig(S, F, J), 11)
+    eng = Engine(S, F, J, 128, 3, B, 0, training=False)
+    eng.load_params(params)
+    pool = ReplicaPool(2, S, F, J, 128, 3, B, 0, merge=3)
+    pool.load_params(params)
+    dev = eng.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    want, got = [], []
+    sizes = [8, 8, 5, 8, 3, 8, 8, 8]                              # groups: (8, 8, 5) (8, 3, 8) and (8, 8) cut short by wait()
+    for i, n in enumerate(sizes):
+        dm, _p, cfgs, coms, _ = make_crops(n, 'icvl', seed=700 + i)
+        d_dm = eng.norm_dm(t(dm), t(coms))
+        want.append(eng.infer(d_dm, t(cfgs), t(coms)).clone())
+        out = torch.full((n, 3 * J), float('nan'), device=dev) if i % 2 else None
+        got.append(pool.submit(d_dm, t(cfgs), t(coms), out=out))
+    for (xyz, ticket), ref in zip(got, want):
+        pool.wait(ticket)
+        torch.cuda.current_stream(dev).synchronize()
+        a, b = xyz.cpu().numpy(), ref.cpu().numpy()
+        assert a.shape == b.shape and np.isfinite(a).all()
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-3)       # mm
+    # a group still filling when the caller is done: flush() launches it
+    xyz, _ticket = pool.submit(d_dm, t(cfgs), t(coms))
+    pool.flush()
+    torch.cuda.synchronize(dev)
+    np.testing.assert_allclose(xyz.cpu().numpy(), want[-1].cpu().numpy(), rtol=0, atol=2e-3)
+    with pytest.raises(ValueError):
+        dm, _p, cfgs, coms, _ = make_crops(B + 1, 'icvl', seed=1)
+        pool.submit(t(dm), t(cfgs), t(coms))
+    pool.close()
+    eng.close()

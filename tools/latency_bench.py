@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run(B, graphs):
     env = dict(os.environ, DR_GRAPHS='1' if graphs else '0')       # the library default is off
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--mode', 'infer', '--batch', str(B), '--steps', '50',
-                          '--warmup', '10', '--no-cpu-baseline', '--no-profile', '--replicas', '1'], env=env, capture_output=True, text=True).stdout
+                          '--warmup', '10', '--no-cpu-baseline', '--no-profile', '--replicas', '1', '--merge', '1'], env=env, capture_output=True, text=True).stdout
     return json.loads(out.strip().splitlines()[-1])
 
 

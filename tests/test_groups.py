@@ -105,3 +105,55 @@ def test_groups_reject_what_the_tiles_cannot_cut(be):
     with pytest.raises(DenseRegError):          # 5 crops are not two equal groups
         h.call('dr_forward_train', 5, be.ptr(dm), 0, None, C.c_uint64(0), be.stream)
     h.close()
+
+
+@pytest.mark.gpu
+def test_groups_window_against_the_oracles_chained_micro_steps(gpu):
+    """The window pass against the ORACLE: G micro-steps of ``oracle.train.loss_and_grads`` with the BatchReNorm state update
+    (``oracle.net.bn_state_update``: moving statistics with zero-debias, r_max / d_max / curr_t) between them, each with its own
+    injected dropout masks -- losses per micro-batch, the summed gradient, and the state after the window."""
+    from densereg_amd.data.synthetic import make_crops
+    from oracle import net, pose, train
+    from oracle.graph import NetConfig
+    from tests.common import flat_grads_by_name
+    be = gpu
+    G, Bg, S, F, J = 3, 8, 2, 32, 4
+    B = G * Bg
+    cfg = NetConfig(S, F, J)
+    dm, poses, cfgs, coms, _ = make_crops(B, 'nyu', seed=91)
+    poses = np.ascontiguousarray(poses[:, :3 * J])
+    ndm = pose.norm_dm(dm, coms)
+    params = net.make_test_params(cfg, ndm[:4], seed=3)
+    rng = np.random.default_rng(1)
+    masks = [rng.integers(0, 2, (B, 32, 32, 512)).astype(np.uint8) for _ in range(2 * S)]      # per dropout layer, all B crops
+    # oracle: the reference's loop
+    p = {k: v.copy() for k, v in params.items()}
+    shadow, want_lo, gsum = {}, [], None
+    for g in range(G):
+        sl = slice(g * Bg, (g + 1) * Bg)
+        lo, gr, upd, _ = train.loss_and_grads(cfg, p, ndm[sl], poses[sl], cfgs[sl], coms[sl], dropout_masks=[m[sl] for m in masks])
+        want_lo.append([lo[k] for k in ('hm', 'hm3', 'um', 'reg')])
+        gsum = gr if gsum is None else {k: gsum[k] + gr[k] for k in gr}
+        net.bn_state_update(p, upd, zero_debias=True, shadow=shadow)
+    # engine: one pass
+    h = be.handle(cfg, B, training=True)
+    h.load_params(params)
+    h.call('dr_finalize_params', be.stream)
+    h.call('dr_zero_grad', be.stream)
+    h.call('dr_set_groups', G)
+    d = [be.dev(a) for a in (ndm, poses, cfgs, coms)]
+    d_mask, d_lo = be.dev(np.ascontiguousarray(np.stack(masks))), be.empty((G, 4))
+    h.call('dr_forward_train', B, be.ptr(d[0]), 1, be.ptr(d_mask), C.c_uint64(0), be.stream)
+    h.call('dr_loss', B, be.ptr(d[0]), be.ptr(d[1]), be.ptr(d[2]), be.ptr(d[3]), be.ptr(d_lo), be.stream)
+    h.call('dr_backward', B, be.stream)
+    be.sync()
+    np.testing.assert_allclose(be.host(d_lo).reshape(G, 4), np.array(want_lo), rtol=3e-4)
+    got = h.read_params()
+    for k in p:
+        if 'moving' in k or k.endswith(('r_max', 'd_max', 'curr_t')):
+            np.testing.assert_allclose(got[k], p[k], rtol=3e-4, atol=5e-5 * max(1.0, float(np.abs(p[k]).max())), err_msg=k)
+    grads = flat_grads_by_name(be, h, cfg)
+    e = np.array([np.abs(grads[n] - gsum[n]).max() / (np.abs(gsum[n]).max() + 1e-12) for n in gsum])
+    print('window gradient vs the oracle (fp32 autograd, %d micro-steps summed): max %.2e median %.2e' % (G, e.max(), np.median(e)))
+    assert e.max() < 1.6e-1 and np.median(e) < 2e-2, (e.max(), np.median(e))         # the bar of tests/test_train_parity.py (1)
+    h.close()

@@ -13,7 +13,7 @@ from densereg_amd import _lib  # noqa: E402
 
 def main():
     lib = _lib.load_debug()
-    B = 40
+    B = int(os.environ.get('PROBE_B', '40'))          # crops per launch (200 = a five-micro-batch window)
     shapes = [(32, 78, 78, 3), (32, 65, 65, 3), (32, 96, 96, 3), (32, 256, 256, 3), (32, 128, 128, 3), (32, 512, 512, 1), (32, 128, 256, 1),
               (32, 78, 256, 1), (32, 128, 128, 1), (32, 128, 64, 1), (16, 64, 64, 3), (16, 128, 64, 1), (8, 64, 64, 3)]
     print('| HxW | Cin | Cout | k | T | slabs | us (kernel + fold) | TFLOP/s |')

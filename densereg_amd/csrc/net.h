@@ -110,13 +110,16 @@ struct ParamInfo {
 
 enum KernelId {
     KID_CONV_128x128, KID_CONV_64x128, KID_CONV_128x64, KID_CONV_64x64, KID_CONV_128x32, KID_CONV_64x64_K64, KID_CONV_SPLITK, KID_CONV_64x96, KID_CONV_64x160, KID_CONV16_64x80, KID_CONV16_64x144, KID_CONV16_64x160, KID_STEM, KID_POOL, KID_UPADD, KID_UVD, KID_COPY,
-    KID_VOTE, KID_BN, KID_WGRAD, KID_WGRAD_FOLD, KID_ELTWISE, KID_LOSS, KID_ADAM, KID_COUNT
+    KID_VOTE, KID_BN, KID_WGRAD, KID_WGRAD_FOLD, KID_ELTWISE, KID_LOSS, KID_ADAM,
+    KID_WGRAD_128, KID_WGRAD_64, KID_WGRAD_ROW, KID_WGRAD_GROUP,          // one row per weight-gradient kernel template (KID_WGRAD: the stem's)
+    KID_COUNT
 };
 static const char* const kKernelNames[KID_COUNT] = {
     "conv_igemm_128x128", "conv_igemm_64x128", "conv_igemm_128x64", "conv_igemm_64x64", "conv_igemm_128x32", "conv_igemm_64x64k64", "conv_splitk_32x32",
     "conv_igemm_64x96", "conv_igemm_64x160", "conv_igemm16_64x80", "conv_igemm16_64x144", "conv_igemm16_64x160",
     "stem_conv", "maxpool",
-    "upsample_add", "uvd", "copy_channels", "vote", "batch_renorm", "conv_wgrad", "wgrad_fold", "eltwise_bwd", "loss", "adam"};
+    "upsample_add", "uvd", "copy_channels", "vote", "batch_renorm", "stem_wgrad", "wgrad_fold", "eltwise_bwd", "loss", "adam",
+    "conv_wgrad_128", "conv_wgrad_64", "conv_wgrad_row96", "conv_wgrad_group"};
 
 struct ProfRecord { rt::Event a, b; int kid; int tag; double flops; double bytes; };
 struct RegSeg;

@@ -37,12 +37,26 @@ def main(fetch_db, write_db):
 
 
 def short_name(n):
+    """rocprof kernel name -> the row name of densereg_profile.h (net.h, kKernelNames): one row per kernel template family"""
     import re
+    m = re.search(r'conv_igemm_kernel<(\d+), (\d+), \d+, \d+, \d+, (\d+), \d+, \d+, \d+, \d+, (\d+)>', n)
+    if m:                                                          # BM, BN, WM, WN, ABL, BK, GL, BF, WK, XB, MF
+        bm, bn, bk, mf = m.groups()
+        return 'conv_igemm%s_%sx%s%s' % ('16' if mf == '16' else '', bm, bn, 'k64' if bk == '64' else '')
     m = re.search(r'conv_igemm_kernel<(\d+), (\d+)', n)
     if m:
         return 'conv_igemm_%sx%s' % (m.group(1), m.group(2))
-    if 'conv_wgrad_kernel' in n or 'conv_wgrad_bf16_kernel' in n or 'conv_wgrad_tr_kernel' in n or 'conv_wgrad_row_kernel' in n or 'conv_wgrad_group_kernel' in n:
-        return 'conv_wgrad'
+    if 'conv_splitk_kernel' in n:
+        return 'conv_splitk_32x32'
+    if 'conv_wgrad_row_kernel' in n:
+        return 'conv_wgrad_row96'
+    if 'conv_wgrad_group_kernel' in n:
+        return 'conv_wgrad_group'
+    m = re.search(r'conv_wgrad(?:_bf16|_tr)?_kernel<(\d+)', n)
+    if m:
+        return 'conv_wgrad_%s' % m.group(1)
+    if 'stem_wgrad_kernel' in n:
+        return 'stem_wgrad'
     return None
 
 

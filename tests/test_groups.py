@@ -1,7 +1,7 @@
-"""Micro-batch groups (``dr_set_groups``): the G micro-steps of one accumulation window as ONE pass of launches, against the
-same G micro-steps run one after the other (the reference's loop, train_single_gpu.py:138-150).  Same arithmetic per
-micro-batch -- statistics, r / d, the clip schedule, the moving-statistics chain -- with sums taken over other tile shapes:
-losses and BatchReNorm state agree to fp32 rounding, the accumulated gradient to the bar of the gradient tests."""
+"""Micro-batch groups (``dr_set_groups``): the G micro-steps of one accumulation window as ONE pass of launches.  Same arithmetic
+per micro-batch as the reference's loop (train_single_gpu.py:138-150) -- statistics, r / d, the clip schedule, the moving-statistics
+chain, the gradient sum -- with sums taken over other tile shapes.  Checked against the oracle's chained micro-steps (emulator and
+GPU) and, on the GPU, against the engine's own micro-step loop."""
 import ctypes as C
 
 import numpy as np
@@ -81,10 +81,13 @@ def _compare(lo_s, g_s, p_s, lo_f, g_f, p_f, params):
     assert np.median(err) <= 1e-5 * scale
 
 
-def test_groups_match_sequential_micro_steps(be):
-    G, Bg = (2, 8) if be.name == 'emu' else (3, 8)
+@pytest.mark.gpu
+def test_groups_match_sequential_micro_steps(gpu):
+    """(GPU only: on the emulator the window pass is checked against the oracle below -- the same statement at half the fibers)"""
+    be = gpu
+    G, Bg = 3, 8
     cfg, params, data = _case(be, G, Bg)
-    windows = 1 if be.name == 'emu' else 2
+    windows = 2
     lo_s, g_s, p_s = _run(be, cfg, params, data, G, Bg, fused=False, windows=windows)
     lo_f, g_f, p_f = _run(be, cfg, params, data, G, Bg, fused=True, windows=windows)
     assert lo_f.shape == (windows * G, 4)
@@ -107,8 +110,7 @@ def test_groups_reject_what_the_tiles_cannot_cut(be):
     h.close()
 
 
-@pytest.mark.gpu
-def test_groups_window_against_the_oracles_chained_micro_steps(gpu):
+def test_groups_window_against_the_oracles_chained_micro_steps(be):
     """The window pass against the ORACLE: G micro-steps of ``oracle.train.loss_and_grads`` with the BatchReNorm state update
     (``oracle.net.bn_state_update``: moving statistics with zero-debias, r_max / d_max / curr_t) between them, each with its own
     injected dropout masks -- losses per micro-batch, the summed gradient, and the state after the window."""
@@ -116,8 +118,7 @@ def test_groups_window_against_the_oracles_chained_micro_steps(gpu):
     from oracle import net, pose, train
     from oracle.graph import NetConfig
     from tests.common import flat_grads_by_name
-    be = gpu
-    G, Bg, S, F, J = 3, 8, 2, 32, 4
+    G, Bg, S, F, J = (2, 8, 1, 8, 2) if be.name == 'emu' else (3, 8, 2, 32, 4)
     B = G * Bg
     cfg = NetConfig(S, F, J)
     dm, poses, cfgs, coms, _ = make_crops(B, 'nyu', seed=91)

@@ -16,12 +16,16 @@ def main():
     B = int(os.environ.get('PROBE_B', '40'))          # crops per launch (200 = a five-micro-batch window)
     shapes = [(32, 78, 78, 3), (32, 65, 65, 3), (32, 96, 96, 3), (32, 256, 256, 3), (32, 128, 128, 3), (32, 512, 512, 1), (32, 128, 256, 1),
               (32, 78, 256, 1), (32, 128, 128, 1), (32, 128, 64, 1), (16, 64, 64, 3), (16, 128, 64, 1), (8, 64, 64, 3)]
+    if os.environ.get('PROBE_SHAPES'):                   # "hw:cin:cout:k,..." instead of the list above
+        shapes = [tuple(int(v) for v in sp.split(':')) for sp in os.environ['PROBE_SHAPES'].split(',')]
+    slabs = [int(v) for v in os.environ.get('PROBE_NS', '0,4,8,16,32,64,128,256').split(',')]
+    tiles = [int(v) for v in os.environ.get('PROBE_T', '128,64,96').split(',')]
     print('| HxW | Cin | Cout | k | T | slabs | us (kernel + fold) | TFLOP/s |')
     print('|---:|---:|---:|---:|---:|---:|---:|---:|')
     for hw, cin, cout, k in shapes:
         flops = 2.0 * B * hw * hw * k * k * cin * cout
-        for T in (128, 64, 96):
-            for ns in (0, 4, 8, 16, 32, 64, 128, 256):
+        for T in tiles:
+            for ns in slabs:
                 us, used = C.c_float(), C.c_int()
                 rc = lib.dr_dbg_wgrad_bench(B, hw, hw, cin, cout, k, T, ns, 10, C.byref(us), C.byref(used))
                 if rc:

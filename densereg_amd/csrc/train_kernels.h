@@ -104,92 +104,73 @@ __device__ __forceinline__ BnChanIn bn_channel_load(const BnTrainParams& p, int 
     in.sh_m = p.shadow_mean[c]; in.sh_v = p.shadow_var[c];
     return in;
 }
-// One micro-batch group of the chain: `in` carries the moving statistics / zero-debias accumulators the group reads and is
-// advanced to what it leaves behind; the group's scale | shift | bnc go to its own copy (gi * stride); the LAST group writes the
-// moving state back.  gi = 0, last = true, cnt = M, the handle's r_max / d_max: the single-batch case, bit for bit.
-__device__ __forceinline__ void bn_channel_coeffs_group(const BnTrainParams& p, int c, BnChanIn& in, double sum, double sq, double cnt, float r_max,
-                                                        float d_max, int gi, bool last) {
-    const float mm = in.mm, mv = in.mv, g = in.g, beta = in.beta, sh_m = in.sh_m, sh_v = in.sh_v;
+// The per-channel arithmetic of one (micro-)batch, ops.py:130-171, in three steps shared by every BatchReNorm forward path (the
+// finalize launch, the self-folding apply pass, the look-back producers, the chain over micro-batch groups):
+//   bn_channel_math     batch moments -> mean, inv_std, the clipped r / d against the moving statistics in `st`, scale | shift
+//   bn_channel_store    the coefficients, to copy `gi` (micro-batch groups: fold_stride / bnc_stride floats apart; 0 otherwise)
+//   bn_channel_advance  `st` -> what this batch leaves behind (moving averages, zero-debias accumulators; `step` = the batch's
+//                       update count, for the debias correction);  bn_channel_store_state writes it back
+struct BnChanOut { float scale, shift, mean, var, inv_std, r, d; };
+__device__ __forceinline__ BnChanOut bn_channel_math(const BnTrainParams& p, const BnChanIn& st, double sum, double sq, double cnt, float r_max,
+                                                     float d_max) {
+    BnChanOut o;
     const double mean_d = sum / cnt;
     double var_d = sq / cnt - mean_d * mean_d;
     if (var_d < 0.0) var_d = 0.0;
-    const float mean = (float)mean_d, var = (float)var_d;
-    const float std_b = sqrtf(var + p.eps);
-    const float inv_std = 1.0f / std_b;
-    const float mstd = sqrtf(mv + p.eps);
+    o.mean = (float)mean_d; o.var = (float)var_d;
+    const float std_b = sqrtf(o.var + p.eps);
+    o.inv_std = 1.0f / std_b;
+    const float mstd = sqrtf(st.mv + p.eps);
     float r = std_b / mstd;
-    r = fminf(fmaxf(r, 1.0f / r_max), r_max);
-    float d = (mean - mm) / mstd;
-    d = fminf(fmaxf(d, -d_max), d_max);
-    const float sc = inv_std * r;
+    o.r = fminf(fmaxf(r, 1.0f / r_max), r_max);
+    float d = (o.mean - st.mm) / mstd;
+    o.d = fminf(fmaxf(d, -d_max), d_max);
+    const float sc = o.inv_std * o.r;
+    o.scale = sc * st.g;
+    o.shift = (o.d - o.mean * sc) * st.g + st.beta;
+    return o;
+}
+__device__ __forceinline__ void bn_channel_store(const BnTrainParams& p, int c, const BnChanOut& o, int gi) {
     float* scale = p.scale + (long)gi * p.fold_stride;
     float* shift = p.shift + (long)gi * p.fold_stride;
     float* bnc = p.bnc + (long)gi * p.bnc_stride;
-    scale[c] = sc * g;
-    shift[c] = (d - mean * sc) * g + beta;
-    bnc[0 * p.C + c] = mean;
-    bnc[1 * p.C + c] = inv_std;
-    bnc[2 * p.C + c] = r;
-    bnc[3 * p.C + c] = d;
+    scale[c] = o.scale;
+    shift[c] = o.shift;
+    bnc[0 * p.C + c] = o.mean;
+    bnc[1 * p.C + c] = o.inv_std;
+    bnc[2 * p.C + c] = o.r;
+    bnc[3 * p.C + c] = o.d;
+}
+__device__ __forceinline__ void bn_channel_advance(const BnTrainParams& p, BnChanIn& st, const BnChanOut& o, int step) {
     const float om = 1.0f - p.decay;
-    float mm_new, mv_new;
     if (p.shadow_step > 0) {
-        const float bm = sh_m - (sh_m - mean) * om;
-        const float bv = sh_v - (sh_v - var) * om;
-        in.sh_m = bm; in.sh_v = bv;
-        const float corr = 1.0f - powf(p.decay, (float)(p.shadow_step + gi));
-        mm_new = bm / corr;
-        mv_new = bv / corr;
+        st.sh_m = st.sh_m - (st.sh_m - o.mean) * om;
+        st.sh_v = st.sh_v - (st.sh_v - o.var) * om;
+        const float corr = 1.0f - powf(p.decay, (float)step);
+        st.mm = st.sh_m / corr;
+        st.mv = st.sh_v / corr;
     } else {
-        mm_new = mm - (mm - mean) * om;
-        mv_new = mv - (mv - var) * om;
-    }
-    in.mm = mm_new; in.mv = mv_new;
-    if (last) {
-        if (p.shadow_step > 0) { p.shadow_mean[c] = in.sh_m; p.shadow_var[c] = in.sh_v; }
-        p.mm_next[c] = mm_new;
-        p.mv_next[c] = mv_new;
+        st.mm = st.mm - (st.mm - o.mean) * om;
+        st.mv = st.mv - (st.mv - o.var) * om;
     }
 }
+__device__ __forceinline__ void bn_channel_store_state(const BnTrainParams& p, int c, const BnChanIn& st) {
+    if (p.shadow_step > 0) { p.shadow_mean[c] = st.sh_m; p.shadow_var[c] = st.sh_v; }
+    p.mm_next[c] = st.mm;
+    p.mv_next[c] = st.mv;
+}
 
+// one batch of M rows: coefficients out; `persist`: this caller also stores them and the updated state
 __device__ __forceinline__ void bn_channel_coeffs(const BnTrainParams& p, int c, const BnChanIn& in, double sum, double sq, float& sc_out, float& sh_out,
                                                   bool persist) {
-    const float mm = in.mm, mv = in.mv, g = in.g, beta = in.beta, sh_m = in.sh_m, sh_v = in.sh_v;
-    const double cnt = (double)p.M;
-    const double mean_d = sum / cnt;
-    double var_d = sq / cnt - mean_d * mean_d;
-    if (var_d < 0.0) var_d = 0.0;
-    const float mean = (float)mean_d, var = (float)var_d;
-    const float std_b = sqrtf(var + p.eps);
-    const float inv_std = 1.0f / std_b;
-    const float mstd = sqrtf(mv + p.eps);
-    float r = std_b / mstd;
-    r = fminf(fmaxf(r, 1.0f / p.r_max), p.r_max);
-    float d = (mean - mm) / mstd;
-    d = fminf(fmaxf(d, -p.d_max), p.d_max);
-    const float sc = inv_std * r;
-    sc_out = sc * g;
-    sh_out = (d - mean * sc) * g + beta;
+    const BnChanOut o = bn_channel_math(p, in, sum, sq, (double)p.M, p.r_max, p.d_max);
+    sc_out = o.scale;
+    sh_out = o.shift;
     if (persist) {
-        p.scale[c] = sc_out;
-        p.shift[c] = sh_out;
-        p.bnc[0 * p.C + c] = mean;
-        p.bnc[1 * p.C + c] = inv_std;
-        p.bnc[2 * p.C + c] = r;
-        p.bnc[3 * p.C + c] = d;
-        const float om = 1.0f - p.decay;
-        if (p.shadow_step > 0) {
-            const float bm = sh_m - (sh_m - mean) * om;
-            const float bv = sh_v - (sh_v - var) * om;
-            p.shadow_mean[c] = bm;
-            p.shadow_var[c] = bv;
-            const float corr = 1.0f - powf(p.decay, (float)p.shadow_step);
-            p.mm_next[c] = bm / corr;
-            p.mv_next[c] = bv / corr;
-        } else {
-            p.mm_next[c] = mm - (mm - mean) * om;
-            p.mv_next[c] = mv - (mv - var) * om;
-        }
+        BnChanIn st = in;
+        bn_channel_store(p, c, o, 0);
+        bn_channel_advance(p, st, o, p.shadow_step);
+        bn_channel_store_state(p, c, st);
     }
 }
 
@@ -257,9 +238,13 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const BnTrainParam
         for (int g = 0; g < p.groups; ++g) {
             double sum, sq;
             fold_partials_wave(p.part, p.part_rows, p.C, c, g * p.rows_per_group, p.rows_per_group, sum, sq);
-            if ((threadIdx.x & 63) == 0)
-                bn_channel_coeffs_group(p, c, st, sum, sq, (double)p.Mg, p.r_max_g[g], p.d_max_g[g], g, g == p.groups - 1);
+            if ((threadIdx.x & 63) == 0) {                    // group g reads the state group g-1 left, in registers
+                const BnChanOut o = bn_channel_math(p, st, sum, sq, (double)p.Mg, p.r_max_g[g], p.d_max_g[g]);
+                bn_channel_store(p, c, o, g);
+                bn_channel_advance(p, st, o, p.shadow_step + g);
+            }
         }
+        if ((threadIdx.x & 63) == 0) bn_channel_store_state(p, c, st);
         return;
     }
     const BnChanIn in = bn_channel_load(p, c);

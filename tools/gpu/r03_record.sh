@@ -5,6 +5,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; G=gpurun_out
 rm -f $G/test_branches.jsonl
 timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=8 > $G/r03_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $G/r03_pytest_gpu.log
+timeout 300 python -m pytest tests/test_groups.py -m gpu -q -s -p no:cacheprovider > $G/r03_groups_test_gpu.log 2>&1
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $G/r03_smoke.log 2>&1; echo "smoke rc=$?" >> $G/r03_smoke.log
 timeout 400 python bench.py --detail $G/r03_detail_train.md > $G/r03_bench_train.json 2> $G/r03_bench_train.err; echo "bench rc=$?" >> $G/r03_bench_train.err
 timeout 300 python bench.py --mode infer --detail $G/r03_detail_infer.md > $G/r03_bench_infer.json 2> $G/r03_bench_infer.err

@@ -21,5 +21,6 @@ cp $G/${R}_detail_train.md profiles/${R}_train_per_layer.md
 cp $G/${R}_detail_infer.md profiles/${R}_infer_per_layer.md
 [ -f $G/${R}_detail_c5_bf16.md ] && cp $G/${R}_detail_c5_bf16.md profiles/${R}_config5_train_per_layer_bf16.md
 [ -f $G/${R}_latency.md ] && cp $G/${R}_latency.md profiles/${R}_infer_latency_by_batch.md
+[ -f $G/${R}_groups_test_gpu.log ] && cp $G/${R}_groups_test_gpu.log profiles/${R}_groups_test_gpu.log
 [ -f $G/test_branches.jsonl ] && cp $G/test_branches.jsonl profiles/${R}_gpu_test_branches.jsonl
 echo refreshed profiles/${R}_*

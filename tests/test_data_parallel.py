@@ -187,3 +187,69 @@ def test_rank_seed_is_injective_over_ranks_and_micro_steps():
     seen = {rank_seed(m, r, 8) for m in range(50) for r in range(8)}
     assert len(seen) == 400
     assert rank_seed(7, 0, 1) == 7                      # one rank: the micro-step counter itself, as before
+
+
+class _ToyEngine:
+    """A stand-in with the trainer's engine interface and a 64-element flat gradient: backward adds a rank- and call-dependent
+    ramp, apply_adam records what it was given.  (The kernels behind a window pass are covered by tests/test_groups.py; this is
+    the N > 1 bookkeeping around it.)"""
+    pipeline = 1
+
+    def __init__(self, rank):
+        self.rank, self.grad, self.calls, self.groups = rank, torch.zeros(64), [], 1
+
+    def flat_view(self, which):
+        return self.grad
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def set_groups(self, g):
+        self.groups = g
+
+    def forward_train(self, dm, mode, mask, seed):
+        self.calls.append(('fwd', dm.shape[0], self.groups, seed))
+
+    def loss(self, dm, pose, cfg, com):
+        return torch.arange(4.0 * self.groups)
+
+    def backward(self, B):
+        self.grad += (self.rank + 1) * self.groups * torch.arange(64.0)          # what `groups` micro-steps accumulate
+
+    def apply_adam(self, lr, div, step, clip):
+        self.calls.append(('adam', self.grad.clone(), div, step))
+
+
+def _window_worker(rank, world, init_file, out_dir):
+    sys.path.insert(0, ROOT)
+    dist.init_process_group('gloo', init_method='file://' + init_file, rank=rank, world_size=world)
+    from densereg_amd.parallel import DataParallelTrainer
+    eng = _ToyEngine(rank)
+    tr = DataParallelTrainer(eng, dataset='nyu', sub_batch=5, dist=dist)
+    dm = torch.zeros(5 * 8, 4, 4)
+    losses = tr.window_step(dm, dm, dm, dm, seed=3, dropout_mode=2)
+    assert tuple(losses.shape) == (5, 4) and tr.micro == 5 and tr.global_step == 1 and eng.groups == 1
+    fwd = [c for c in eng.calls if c[0] == 'fwd']
+    adam = [c for c in eng.calls if c[0] == 'adam']
+    assert len(fwd) == 1 and fwd[0][1:3] == (40, 5) and len(adam) == 1
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), grad=adam[0][1].numpy(), div=adam[0][2], seed=fwd[0][3],
+             after=eng.grad.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_window_step_all_reduces_once_per_window():
+    """SURVEY 8(e) with the accumulation window as one pass (``DataParallelTrainer.window_step``): one all-reduce(sum) of the
+    flat gradient per window, division by sub_batch x world inside the optimizer kernel, per-rank dropout seeds, accumulator
+    cleared afterwards -- world 2 over gloo."""
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, 'rdzv')
+        mp.spawn(_window_worker, args=(world, init_file, d), nprocs=world, join=True)
+        r0 = dict(np.load(os.path.join(d, 'rank0.npz')))
+        r1 = dict(np.load(os.path.join(d, 'rank1.npz')))
+    want = (1 + 2) * 5 * np.arange(64.0)                 # both ranks' five micro-steps, summed
+    np.testing.assert_array_equal(r0['grad'], want)
+    np.testing.assert_array_equal(r1['grad'], want)
+    assert float(r0['div']) == float(r1['div']) == 10.0
+    assert int(r0['seed']) != int(r1['seed'])            # parallel.rank_seed
+    assert not r0['after'].any() and not r1['after'].any()

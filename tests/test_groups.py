@@ -125,6 +125,54 @@ def test_groups_match_sequential_micro_steps_on_the_bf16_matrix_cores(gpu):
             np.testing.assert_array_equal(p_f[k], p_s[k], err_msg=k)
 
 
+@pytest.mark.gpu
+def test_groups_window_is_bit_reproducible_at_eight_groups_with_dropout(gpu):
+    """The largest window (G = 8) with ``DR_DROPOUT_RNG``: finite, every micro-batch has its own loss row, the same bits on two
+    fresh handles (no floating-point atomics anywhere on the path, per-group sums in fixed order), another seed gives other masks,
+    and a repeated loss + backward on the same forward doubles the accumulated gradient."""
+    from densereg_amd.data.synthetic import make_crops
+    from oracle import net, pose
+    from oracle.graph import NetConfig
+    be = gpu
+    G, Bg, S, F, J = 8, 8, 1, 64, 14
+    B = G * Bg
+    cfg = NetConfig(S, F, J)
+    dm, poses, cfgs, coms, _ = make_crops(B, 'nyu', seed=17)
+    data = (pose.norm_dm(dm, coms), np.ascontiguousarray(poses[:, :3 * J]), cfgs, coms)
+    params = net.make_test_params(cfg, data[0][:4], seed=9)
+
+    def run(seed, twice=False):
+        h = be.handle(cfg, B, training=True)
+        h.load_params(params)
+        h.call('dr_finalize_params', be.stream)
+        h.call('dr_zero_grad', be.stream)
+        h.call('dr_set_groups', G)
+        d = [be.dev(np.ascontiguousarray(a)) for a in data]
+        d_lo = be.empty((G, 4))
+        h.call('dr_forward_train', B, be.ptr(d[0]), 2, None, C.c_uint64(seed), be.stream)
+        for _ in range(2 if twice else 1):
+            h.call('dr_loss', B, be.ptr(d[0]), be.ptr(d[1]), be.ptr(d[2]), be.ptr(d[3]), be.ptr(d_lo), be.stream)
+            h.call('dr_backward', B, be.stream)
+        be.sync()
+        addr, n = h.flat('grad')
+        out = be.host(d_lo).reshape(G, 4).copy(), _flat_rw(be, addr, n)[0]().copy(), h.read_params()
+        h.close()
+        return out
+    lo_a, g_a, p_a = run(5)
+    lo_b, g_b, p_b = run(5)
+    assert np.isfinite(lo_a).all() and np.isfinite(g_a).all() and np.abs(g_a).max() > 0
+    assert len({tuple(r[:3]) for r in lo_a.tolist()}) == G              # eight different micro-batches, eight different rows
+    assert np.all(lo_a[:, 3] == lo_a[0, 3])                             # the regulariser is the same for all of them
+    np.testing.assert_array_equal(lo_a, lo_b)
+    np.testing.assert_array_equal(g_a, g_b)
+    for k in p_a:
+        np.testing.assert_array_equal(p_a[k], p_b[k], err_msg=k)
+    lo_c, g_c, _ = run(6)
+    assert np.abs(lo_c - lo_a).max() > 0                                # other seed, other masks
+    _, g_2, _ = run(5, twice=True)
+    np.testing.assert_allclose(g_2, 2.0 * g_a, rtol=0, atol=1e-4 * float(np.abs(g_a).max()))
+
+
 def test_groups_reject_what_the_tiles_cannot_cut(be):
     from oracle.graph import NetConfig
     cfg = NetConfig(1, 8, 2)

@@ -813,11 +813,18 @@ struct LossParams {
 
 __global__ __launch_bounds__(256) void loss_kernel(const LossParams p) {
 #pragma clang fp contract(off)
+    // One thread per (pixel, joint), joints fastest: the threads of a wave read and write consecutive channels of consecutive
+    // pixels (the maps are [pixel][J] / [pixel][3J]), every map element is touched by exactly one thread.  (One thread per pixel
+    // walking the joints, one joint per workgroup row: a wave touched 64 cache lines for 64 floats, and the J rows of the grid read
+    // every line J times -- 480 us for a 200-crop window, 230 MB of maps.)  The per-pixel point cloud is recomputed per joint: a
+    // dozen flops.
     __shared__ double red[3][4];
     const int npix = p.h * p.w;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     double l_hm = 0.0, l_hm3 = 0.0, l_um = 0.0;
-    if (i < p.B * npix) {
+    if (idx < (long)p.B * npix * p.J) {
+        const int j = (int)(idx % p.J);
+        const int i = (int)(idx / p.J);
         const int b = i / npix, px = i % npix;
         const float* cfg = p.cfg + b * 6;
         const float cx0 = p.com[b * 3 + 0], cy0 = p.com[b * 3 + 1], cz0 = p.com[b * 3 + 2];
@@ -833,39 +840,34 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams p) {
         X = (X - cx0) / 100.0f;
         Y = (Y - cy0) / 100.0f;
         const float Z = (zz - cz0) / 100.0f;
-        // gridDim.y = 1: this thread walks all joints; gridDim.y = J: one joint per workgroup row (14-21x the threads: the
-        // per-pixel kernel was a 150 us chain of dependent strided loads and stores on 160 workgroups)
-        const int j_lo = gridDim.y > 1 ? (int)blockIdx.y : 0, j_hi = gridDim.y > 1 ? (int)blockIdx.y + 1 : p.J;
-        for (int j = j_lo; j < j_hi; ++j) {
-            const float* ps = p.pose + (long)b * 3 * p.J + 3 * j;
-            // 2D cone (:225-242)
-            const float u = ps[0] * fx / ps[2] + cx;
-            const float v = ps[1] * fy / ps[2] + cy;
-            const float du = xx - u, dv = yy - v;
-            const float gt_hm = fmaxf(4.0f - sqrtf(du * du + dv * dv), 0.0f) / 4.0f;
-            // 3D offsets (:338-346)
-            const float ox = (ps[0] - cx0) / 100.0f - X;
-            const float oy = (ps[1] - cy0) / 100.0f - Y;
-            const float oz = (ps[2] - cz0) / 100.0f - Z;
-            const float dist = sqrtf((ox * ox + oy * oy) + oz * oz);
-            const float gt_hm3 = fmaxf((0.8f - dist) / 0.8f, 0.0f);
-            const float d3 = 0.8f - gt_hm3 * 0.8f;
-            const bool near = d3 < (0.8f - 1e-2f);
-            const float ux = near ? ox / d3 : 0.0f, uy = near ? oy / d3 : 0.0f, uz = near ? oz / d3 : 0.0f;
-            for (int s = 0; s < p.S; ++s) {
-                const long m = i;
-                const float e1 = p.hm[s].p[m * p.hm[s].cs + p.hm[s].coff + j] - gt_hm;
-                const float e2 = p.hm3[s].p[m * p.hm3[s].cs + p.hm3[s].coff + j] - gt_hm3;
-                const float* um = p.um[s].p + m * p.um[s].cs + p.um[s].coff + 3 * j;
-                const float e3 = um[0] - ux, e4 = um[1] - uy, e5 = um[2] - uz;
-                p.dhm[s].p[m * p.dhm[s].cs + p.dhm[s].coff + j] = e1;
-                p.dhm3[s].p[m * p.dhm3[s].cs + p.dhm3[s].coff + j] = e2;
-                float* dum = p.dum[s].p + m * p.dum[s].cs + p.dum[s].coff + 3 * j;
-                dum[0] = e3; dum[1] = e4; dum[2] = e5;
-                l_hm += 0.5 * (double)e1 * e1;
-                l_hm3 += 0.5 * (double)e2 * e2;
-                l_um += 0.5 * ((double)e3 * e3 + (double)e4 * e4 + (double)e5 * e5);
-            }
+        const float* ps = p.pose + (long)b * 3 * p.J + 3 * j;
+        // 2D cone (:225-242)
+        const float u = ps[0] * fx / ps[2] + cx;
+        const float v = ps[1] * fy / ps[2] + cy;
+        const float du = xx - u, dv = yy - v;
+        const float gt_hm = fmaxf(4.0f - sqrtf(du * du + dv * dv), 0.0f) / 4.0f;
+        // 3D offsets (:338-346)
+        const float ox = (ps[0] - cx0) / 100.0f - X;
+        const float oy = (ps[1] - cy0) / 100.0f - Y;
+        const float oz = (ps[2] - cz0) / 100.0f - Z;
+        const float dist = sqrtf((ox * ox + oy * oy) + oz * oz);
+        const float gt_hm3 = fmaxf((0.8f - dist) / 0.8f, 0.0f);
+        const float d3 = 0.8f - gt_hm3 * 0.8f;
+        const bool near = d3 < (0.8f - 1e-2f);
+        const float ux = near ? ox / d3 : 0.0f, uy = near ? oy / d3 : 0.0f, uz = near ? oz / d3 : 0.0f;
+        for (int s = 0; s < p.S; ++s) {
+            const long m = i;
+            const float e1 = p.hm[s].p[m * p.hm[s].cs + p.hm[s].coff + j] - gt_hm;
+            const float e2 = p.hm3[s].p[m * p.hm3[s].cs + p.hm3[s].coff + j] - gt_hm3;
+            const float* um = p.um[s].p + m * p.um[s].cs + p.um[s].coff + 3 * j;
+            const float e3 = um[0] - ux, e4 = um[1] - uy, e5 = um[2] - uz;
+            p.dhm[s].p[m * p.dhm[s].cs + p.dhm[s].coff + j] = e1;
+            p.dhm3[s].p[m * p.dhm3[s].cs + p.dhm3[s].coff + j] = e2;
+            float* dum = p.dum[s].p + m * p.dum[s].cs + p.dum[s].coff + 3 * j;
+            dum[0] = e3; dum[1] = e4; dum[2] = e5;
+            l_hm += 0.5 * (double)e1 * e1;
+            l_hm3 += 0.5 * (double)e2 * e2;
+            l_um += 0.5 * ((double)e3 * e3 + (double)e4 * e4 + (double)e5 * e5);
         }
     }
     // block reduction: wave shuffle, then 4 waves through LDS
@@ -880,8 +882,8 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams p) {
     __syncthreads();
     if (threadIdx.x < 3) {
         const double s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-        // [3][gridDim.y * gridDim.x] partial rows, summed in index order by losses_out_kernel
-        p.acc[((long)threadIdx.x * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+        // [3][gridDim.x] partial rows, summed in index order by losses_out_kernel
+        p.acc[(long)threadIdx.x * gridDim.x + blockIdx.x] = s;
     }
 }
 
@@ -911,21 +913,20 @@ __global__ __launch_bounds__(256) void reg_grad_kernel(const float* param, float
 }
 // Sums the partial rows of the loss kernels in a fixed order (1168 same-address fp64 atomics cost 100 us here and made
 // the reported loss depend on their order).  loss_part = [3][n_loss] rows of loss_kernel, reg_part = n_reg partials.
-// Micro-batch groups: workgroup g writes out[4 g ..] from the pixel blocks of its group -- loss_part rows are [3][J][nblk] and a
-// group owns nblk / gridDim.x consecutive blocks of every joint's row (gridDim.x = 1: all of them, in index order as before).
+// Micro-batch groups: workgroup g writes out[4 g ..] from its group's n_loss / gridDim.x consecutive rows (the loss kernel's
+// threads are ordered by pixel, a group's pixels fill whole blocks); the regulariser is the same for every group.
 __global__ __launch_bounds__(256) void losses_out_kernel(const double* loss_part, int n_loss, const double* reg_part, int n_reg,
-                                                         float* out, int nblk) {
+                                                         float* out) {
     // one wave per loss term (the regulariser's ~9000 partials were a 146-deep chain of dependent loads on one wave: 38 us);
     // per wave: lane-strided loads, four independent accumulators, fixed shuffle tree -- the order never depends on timing
     const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
-    const double* src = t < 3 ? loss_part + (long)t * n_loss : reg_part;
-    const int bpg = nblk / (int)gridDim.x, g0 = (int)blockIdx.x * bpg;                 // this group's blocks of each joint row
-    const int n = t < 3 ? (n_loss / nblk) * bpg : n_reg;
-    auto at = [&](int i) -> double { return t < 3 ? src[(long)(i / bpg) * nblk + g0 + i % bpg] : src[i]; };
+    const int bpg = n_loss / (int)gridDim.x;
+    const double* src = t < 3 ? loss_part + (long)t * n_loss + (long)blockIdx.x * bpg : reg_part;
+    const int n = t < 3 ? bpg : n_reg;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int i = lane;
-    for (; i + 3 * 64 < n; i += 4 * 64) { a0 += at(i); a1 += at(i + 64); a2 += at(i + 128); a3 += at(i + 192); }
-    for (; i < n; i += 64) a0 += at(i);
+    for (; i + 3 * 64 < n; i += 4 * 64) { a0 += src[i]; a1 += src[i + 64]; a2 += src[i + 128]; a3 += src[i + 192]; }
+    for (; i < n; i += 64) a0 += src[i];
     double a = (a0 + a1) + (a2 + a3);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);

@@ -292,15 +292,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(fn):
+    def timed(fn, steps=None, warmup=None):
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize, MAX over ranks (seconds)."""
-        for i in range(args.warmup):
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
+        for i in range(warmup):
             fn(i)
         flush()
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            fn(args.warmup + i)
+        for i in range(steps):
+            fn(warmup + i)
         flush()
         barrier()
         el = time.perf_counter() - t0
@@ -380,21 +382,47 @@ def main():
         idm, _ip, icfg, icom, _ = make_crops(B, 'icvl', seed=20240, rank=rank, hw=HW)
         i_dm, i_cfg, i_com = ieng.norm_dm(t(idm), t(icom)), t(icfg), t(icom)
         i_xyz = ieng.new(B, 3 * Ji)
-        idt1 = timed(lambda i: ieng.infer(i_dm, i_cfg, i_com, out=i_xyz))
+        # This leg runs its OWN number of batches: a merged pool launches once per `replicas x merge` batches, so the contract's
+        # default of 20 steps would be four launches, two per replica -- ramp, not steady state (the driver's 20-step line said
+        # 8370 crops/s where 100 steps say 10.4k).  At least 100 timed batches after at least 10 warm-up ones, whatever --steps is;
+        # the leg reports the counts it used.
+        fv_steps, fv_warmup = max(args.steps, 100), max(args.warmup, 10)
+        idt1 = timed(lambda i: ieng.infer(i_dm, i_cfg, i_com, out=i_xyz), fv_steps, fv_warmup)
         idt = idt1
+
+        def latency_ms(submit_group, n=15):
+            """unloaded latency: the device is idle, a batch (or the batches of one merged group) is handed in, the host waits for
+            the FIRST batch's joints -- median over n repetitions"""
+            ts = []
+            for _ in range(n + 2):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                submit_group()
+                torch.cuda.synchronize(dev)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return float(np.median(ts[2:]))
+        lat = {'one_engine_one_batch': latency_ms(lambda: ieng.infer(i_dm, i_cfg, i_com, out=i_xyz))}
         if args.replicas * args.merge > 1:
             ipool, iout = make_pool(Ji)
             live_pools.append(ipool)
-            idt = timed(lambda i: ipool.submit(i_dm, i_cfg, i_com, out=iout[i % len(iout)]))
+            idt = timed(lambda i: ipool.submit(i_dm, i_cfg, i_com, out=iout[i % len(iout)]), fv_steps, fv_warmup)
+
+            def one_group():
+                tk = [ipool.submit(i_dm, i_cfg, i_com, out=iout[k])[1] for k in range(args.merge)]
+                ipool.wait(tk[0])
+            # a batch of a merged group leaves with its group: the launch of `merge` x B crops, plus -- in a serving loop -- the
+            # wait for the group to fill, which depends on the arrival rate and is not part of this figure
+            lat['merged_group_of_%d_batches' % args.merge] = latency_ms(one_group)
             live_pools.remove(ipool)
             ipool.close()
         fwd_vote = {'metric': 'depth-crops/sec fwd(eval)+vote, %d-stack fea=%d @%dx%d' % (S, F, HW, HW),
-                    'value': B * world * args.steps / idt, 'unit': 'crops/s', 'ms_per_step': idt / args.steps * 1e3,
-                    'steps': args.steps, 'warmup': args.warmup,
+                    'value': B * world * fv_steps / idt, 'unit': 'crops/s', 'ms_per_step': idt / fv_steps * 1e3,
+                    'steps': fv_steps, 'warmup': fv_warmup,
                     'workload': 'ICVL S=%d F=%d J=%d B=%d/GPU %dx%d forward(eval) + vote -> xyz mm, %d GPU(s) x %d replica(s) per GPU '
                                 '(each on its own stream; a replica runs %d consecutive batches as one launch)' % (S, F, Ji, B, HW, HW, world, args.replicas, args.merge),
                     'replicas_per_gpu': args.replicas, 'batches_per_launch': args.merge,
-                    'single_replica': {'value': B * world * args.steps / idt1, 'ms_per_step': idt1 / args.steps * 1e3},
+                    'single_replica': {'value': B * world * fv_steps / idt1, 'ms_per_step': idt1 / fv_steps * 1e3},
+                    'latency_ms_unloaded': lat,
                     'conv_gflop_per_crop_fwd': ieng.conv_flops_per_crop() / 1e9}
         ieng.close()
 

@@ -2,7 +2,7 @@
 
 ``profiles/pmc_traffic.json`` (HBM bytes per launch from rocprofv3 PMC passes) is produced outside the benchmark process;
 ``bench.py`` may only quote it while the kernels it describes are the kernels of the build it is running.  The stamp is a hash
-of the kernel sources with comments and whitespace removed, so an edit to a comment does not invalidate a measurement and an
+of the kernel sources and of the launch-side sources (tile selection, executors) with comments and whitespace removed, so an edit to a comment does not invalidate a measurement and an
 edit to the code does.
 """
 from __future__ import annotations
@@ -12,8 +12,11 @@ import os
 import re
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+# the kernels, and the host code that decides WHICH kernel runs with what grid (tile selection, slab plans, split-K fallbacks,
+# the executors): an edit there changes the bytes per launch just as an edit to a kernel does
 KERNEL_SOURCES = ('conv_igemm.h', 'conv_epilogue.inc', 'conv_splitk.h', 'conv_wgrad.h', 'conv_wgrad_bf16.h', 'conv_wgrad_tr.h',
-                  'train_kernels.h', 'kernels_misc.h', 'dr_platform.h')
+                  'train_kernels.h', 'kernels_misc.h', 'dr_platform.h', 'vote.h',
+                  'densereg.cpp', 'train_exec.inc', 'pipeline.inc', 'net.h')
 
 
 def _strip(src: str) -> str:

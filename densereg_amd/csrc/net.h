@@ -144,7 +144,8 @@ struct StepSlot {
     hipStream_t stream = nullptr;                            // library-owned (two slots), else the caller's stream is used
     hipStream_t wg_stream = nullptr; rt::Event wg_ready{}, wg_done{};
     rt::Event in_ev{}, fwd_done{}, loss_done{}, step_done{};
-    bool fwd_recorded = false, step_recorded = false;        // the events above carry a record
+    bool fwd_recorded = false, step_recorded = false, loss_recorded = false;   // the events above carry a record
+    bool events_live = false;                                // in_ev / fwd_done / loss_done / step_done exist (created with the slot streams)
     bool grads_dirty = false;                                // gacc holds contributions not yet folded into slot 0's (dr_sync_grads)
     bool owns = false;                                       // slot 1: buffers allocated by dr_set_pipeline (slot 0 aliases the handle's)
 };

@@ -126,11 +126,28 @@ class DataParallelTrainer:
         """A whole accumulation window at once: the tensors hold ``sub_batch`` consecutive micro-batches, the engine runs them as
         micro-batch groups in ONE pass of launches (``Engine.set_groups``: per-micro-batch BatchReNorm statistics, the state
         chained in order, the gradient sum) and the optimizer step follows -- what ``sub_batch`` calls of ``micro_step`` do, with
-        ``sub_batch`` times the rows per kernel launch.  Returns the loss terms ``[sub_batch, 4]`` (device)."""
+        ``sub_batch`` times the rows per kernel launch.  Returns the loss terms ``[sub_batch, 4]`` (device).  The optimizer step has
+        been applied when this returns: a caller that checks the losses for NaN (the reference asserts after every micro-step,
+        train_single_gpu.py:147) sees them one update later than with ``micro_step``.  Windows the one-pass form cannot take
+        (``Engine.groups_supported``) run as ``sub_batch`` micro-steps instead."""
         eng, G = self.eng, self.sub_batch
         B = dm_norm.shape[0]
         if B % G:
             raise ValueError('window_step: %d crops are not %d micro-batches' % (B, G))
+        if self.micro % G:
+            raise ValueError('window_step: %d micro-step(s) of an unfinished window are pending' % (self.micro % G))
+        supported = getattr(eng, 'groups_supported', None)
+        if supported is not None and not supported(B // G, G):
+            # what the one-pass window cannot take (micro-batches that are not a multiple of 8 crops, a window larger than the
+            # engine's max_batch, more than 8 micro-batches): the same window as G micro-steps -- same result, G passes of launches
+            Bg, out = B // G, []
+            for g in range(G):
+                sl = slice(g * Bg, (g + 1) * Bg)
+                km = None if keep_mask is None else keep_mask[:, sl].contiguous()       # [dropout layer][crop][h][w][512]
+                out.append(self.micro_step(dm_norm[sl], pose_mm[sl], cfg[sl], com[sl], seed=seed * G + g, dropout_mode=dropout_mode,
+                                           keep_mask=km))
+            import torch
+            return torch.stack([o.reshape(4) for o in out])
         eng.set_groups(G)
         try:
             eng.forward_train(dm_norm, dropout_mode, keep_mask, rank_seed(seed, self.rank, self.world))

@@ -147,9 +147,13 @@ int dr_zero_grad(dr_handle* h, dr_stream stream);                       /* reset
  * BatchReNorm moving statistics (forward k+1 reads what forward k wrote, slim/ops.py:134-162) and the gradient sum.  With
  * depth 2 the handle owns two sets of per-micro-step buffers and two library streams: dr_forward_train / dr_loss / dr_backward
  * of micro-step k are enqueued on set k % 2's stream (after whatever `stream` holds at the time of the call), forward k+1
- * starts when forward k has finished, and the two kernel streams overlap.  Inputs are copied at enqueue time; dr_loss orders
- * `stream` behind the loss kernels (losses_dev is valid in stream order); dr_zero_grad, dr_sync_grads and dr_apply_adam order
- * `stream` behind every micro-step in flight.  Each set accumulates its own gradient, summed in a fixed order by
+ * starts when forward k has finished, and the two kernel streams overlap.  The crops of dr_forward_train and the poses / camera
+ * parameters / centres of mass of dr_loss are copied in `stream`'s order at the time of the call (the caller may recycle those
+ * buffers right behind the call, on `stream`); a DR_DROPOUT_MASK keep mask is NOT copied (it is a test hook of 2 KB per map pixel):
+ * it must stay untouched until `stream` has been ordered behind the micro-step's dr_backward (dr_sync_grads, dr_zero_grad,
+ * dr_apply_adam).  dr_loss orders `stream` behind the loss kernels when losses_dev is given (it is valid in stream order);
+ * dr_zero_grad, dr_sync_grads and dr_apply_adam order `stream` behind every micro-step in flight.  A rejected call (DR_E_INVALID /
+ * DR_E_UNSUPPORTED from dr_forward_train) leaves the handle where it was: the previous micro-step can still be continued.  Each set accumulates its own gradient, summed in a fixed order by
  * dr_sync_grads / dr_apply_adam: results are deterministic, and equal depth 1's up to the rounding of that one addition.
  * Entry points that read the handle's buffers from the host (dr_read_param, dr_read_activation, ...) drain the pipeline first. */
 int dr_set_pipeline(dr_handle* h, int depth);

@@ -235,18 +235,34 @@ rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 local = int(os.environ['LOCAL_RANK'])
 torch.cuda.set_device(local)
 dist.init_process_group('nccl', rank=rank, world_size=world)
-S, F, J, B, SUB = 1, 32, 4, 3, 2
+S, F, J, B, SUB = %(shape)s
+MB = B * SUB if %(mode)r == 'window' else B      # crops a handle must hold
 params = net.init_params(NetConfig(S, F, J), 11)
 def crops(r, i):
     dm, poses, cfgs, coms, _ = make_crops(B, 'icvl', seed=300 + 10 * i, rank=r)
     return dm, np.ascontiguousarray(poses[:, :3 * J]), cfgs, coms
-def run(eng, tr, r):
+MODE = %(mode)r
+def run(eng, tr, r, step=True):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    if MODE == 'window':
+        # the default training path: the SUB micro-batches of the accumulation window side by side, one pass of launches
+        parts = [crops(r, i) for i in range(SUB)]
+        dm, poses, cfgs, coms = (np.concatenate([p[k] for p in parts]) for k in range(4))
+        ndm = eng.norm_dm(t(dm), t(coms))
+        if step:
+            tr.window_step(ndm, t(poses), t(cfgs), t(coms), seed=0, dropout_mode=0)
+        else:                                   # the window's gradient without the optimizer step behind it
+            eng.set_groups(SUB)
+            eng.forward_train(ndm, 0, None, 0)
+            eng.loss(ndm, t(poses), t(cfgs), t(coms))
+            eng.backward(ndm.shape[0])
+            eng.set_groups(1)
+        return
     for i in range(SUB):
         dm, poses, cfgs, coms = crops(r, i)
         ndm = eng.norm_dm(t(dm), t(coms))
         tr.micro_step(ndm, t(poses), t(cfgs), t(coms), seed=i, dropout_mode=0)
-eng = Engine(S, F, J, 128, 3, B, local, training=True)
+eng = Engine(S, F, J, 128, 3, MB, local, training=True)
 eng.load_params(params)
 tr = DataParallelTrainer(eng, dataset='nyu', sub_batch=SUB, dist=dist)
 run(eng, tr, rank)
@@ -258,14 +274,15 @@ if rank == 0:
     # BatchReNorm statistics), summed, divided by sub_batch * world inside the fused clip + Adam kernel
     total = None
     for r in range(world):
-        e = Engine(S, F, J, 128, 3, B, local, training=True)
+        e = Engine(S, F, J, 128, 3, MB, local, training=True)
         e.load_params(params)
         t2 = DataParallelTrainer(e, dataset='nyu', sub_batch=SUB + 1)        # never reaches its own optimizer step
-        run(e, t2, r)
+        run(e, t2, r, step=False)
+        e.sync_grads()
         g = e.flat_view('grad').clone()
         total = g if total is None else total + g
         e.close()
-    ref = Engine(S, F, J, 128, 3, B, local, training=True)
+    ref = Engine(S, F, J, 128, 3, MB, local, training=True)
     ref.load_params(params)
     ref.flat_view('grad').copy_(total)
     from densereg_amd.parallel import GRAD_CLIP, learning_rate
@@ -276,20 +293,30 @@ dist.destroy_process_group()
 '''
 
 
-def test_rccl_two_rank_step_matches_single_process(tmp_path):
-    """One optimizer step of ``DataParallelTrainer`` on two GPUs over RCCL (train_multi_gpu.py:16-39 semantics)."""
+def _rccl_two_ranks(tmp_path, mode, shape, port):
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip('needs two GPUs (the driver runs the N > 1 path on an 8-GPU node)')
     script = tmp_path / 'worker.py'
-    script.write_text(_RCCL_WORKER % {'root': ROOT, 'out': str(tmp_path)})
+    script.write_text(_RCCL_WORKER % {'root': ROOT, 'out': str(tmp_path), 'mode': mode, 'shape': '%d, %d, %d, %d, %d' % shape})
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     rc = subprocess.call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-                          '127.0.0.1', '--master-port', '29533', str(script)], env=env, timeout=600)
+                          '127.0.0.1', '--master-port', str(port), str(script)], env=env, timeout=600)
     assert rc == 0
     r0, r1, ref = (dict(np.load(tmp_path / n)) for n in ('rank0.npz', 'rank1.npz', 'ref.npz'))
     from oracle.graph import NetConfig, trainable_names
-    names = [n.replace('/', '|') for n in trainable_names(NetConfig(1, 32, 4))]
+    names = [n.replace('/', '|') for n in trainable_names(NetConfig(*shape[:3]))]
     for k in names:
         np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)                # replicas stay in lock-step
         np.testing.assert_allclose(r0[k], ref[k], rtol=1e-5, atol=2e-6, err_msg=k)
+
+
+def test_rccl_two_rank_step_matches_single_process(tmp_path):
+    """One optimizer step of ``DataParallelTrainer.micro_step`` x sub_batch on two GPUs over RCCL (train_multi_gpu.py:16-39)."""
+    _rccl_two_ranks(tmp_path, 'micro', (1, 32, 4, 3, 2), 29533)
+
+
+def test_rccl_two_rank_window_step_matches_single_process(tmp_path):
+    """The same through ``DataParallelTrainer.window_step`` -- the default training path: each rank runs its accumulation window
+    (2 micro-batches of 8 crops) as ONE pass of launches (``dr_set_groups``), then one all-reduce(sum) and the optimizer step."""
+    _rccl_two_ranks(tmp_path, 'window', (1, 32, 4, 8, 2), 29534)

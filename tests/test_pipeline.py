@@ -198,6 +198,49 @@ def test_pipeline_ragged_batches_and_depth_switch(gpu):
     assert np.abs(g_switch - g_ref).max() <= 4e-6 * sc + 1e-12
 
 
+def test_rejected_forward_leaves_the_slots_alone_and_inputs_may_be_recycled(be):
+    """Depth 2: (a) a dr_forward_train the library rejects (batch above max_batch) moves no state -- the micro-step enqueued before
+    it can still be continued with dr_loss / dr_backward and gives the gradient of an undisturbed run; (b) the caller's crops,
+    poses, camera parameters and centres of mass are copied in the caller's stream order, so overwriting them right behind the
+    calls changes nothing (include/densereg.h); (c) depth 2 -> 1 -> 2 -> close releases every stream and event exactly once."""
+    from densereg_amd._lib import DenseRegError
+    cfg, params, batches, B = _case(be)
+
+    def run(disturb):
+        h = be.handle(cfg, B, training=True)
+        h.call('dr_set_pipeline', 2)
+        h.load_params(params)
+        h.call('dr_finalize_params', be.stream)
+        h.call('dr_zero_grad', be.stream)
+        for i in range(2):
+            bufs = [be.dev(np.ascontiguousarray(a)) for a in batches[i]]
+            h.call('dr_forward_train', B, be.ptr(bufs[0]), 0, None, C.c_uint64(0), be.stream)
+            if disturb:
+                with pytest.raises(DenseRegError):
+                    h.call('dr_forward_train', B + 1, be.ptr(bufs[0]), 0, None, C.c_uint64(0), be.stream)
+            h.call('dr_loss', B, be.ptr(bufs[0]), be.ptr(bufs[1]), be.ptr(bufs[2]), be.ptr(bufs[3]), None, be.stream)
+            if disturb:                                  # recycle the inputs in stream order, right behind the calls
+                for b in bufs:
+                    if be.name == 'emu':
+                        b[...] = 7.0
+                    else:
+                        b.fill_(7.0)
+            h.call('dr_backward', B, be.stream)
+        h.call('dr_sync_grads', be.stream)
+        be.sync()
+        addr, n = h.flat('grad')
+        g = _flat_rw(be, addr, n)[0]().copy()
+        if disturb:
+            h.call('dr_set_pipeline', 1)
+            h.call('dr_set_pipeline', 2)
+            h.call('dr_set_pipeline', 1)
+        h.close()
+        return g
+    g_ref, g_got = run(False), run(True)
+    assert np.isfinite(g_ref).all() and np.abs(g_ref).max() > 0
+    np.testing.assert_array_equal(g_got, g_ref)
+
+
 @pytest.mark.gpu
 def test_inference_replicas_equal_one_engine(gpu):
     """densereg_amd/serving.py: k replicas (same weights, one stream each) taking batches in turn give, batch by batch, the

@@ -8,6 +8,7 @@
 #include "../../include/densereg.h"
 #include "dr_platform.h"
 #include "conv_wgrad.h"
+#include "conv_wgrad16.h"
 #include "kernels_misc.h"
 
 namespace dr {
@@ -111,7 +112,7 @@ struct ParamInfo {
 enum KernelId {
     KID_CONV_128x128, KID_CONV_64x128, KID_CONV_128x64, KID_CONV_64x64, KID_CONV_128x32, KID_CONV_64x64_K64, KID_CONV_SPLITK, KID_CONV_64x96, KID_CONV_64x160, KID_CONV16_64x80, KID_CONV16_64x144, KID_CONV16_64x160, KID_STEM, KID_POOL, KID_UPADD, KID_UVD, KID_COPY,
     KID_VOTE, KID_BN, KID_WGRAD, KID_WGRAD_FOLD, KID_ELTWISE, KID_LOSS, KID_ADAM,
-    KID_WGRAD_128, KID_WGRAD_64, KID_WGRAD_ROW, KID_WGRAD_GROUP,          // one row per weight-gradient kernel template (KID_WGRAD: the stem's)
+    KID_WGRAD_128, KID_WGRAD_64, KID_WGRAD_ROW, KID_WGRAD_GROUP, KID_WGRAD_16,   // one row per weight-gradient kernel template (KID_WGRAD: the stem's)
     KID_COUNT
 };
 static const char* const kKernelNames[KID_COUNT] = {
@@ -119,7 +120,7 @@ static const char* const kKernelNames[KID_COUNT] = {
     "conv_igemm_64x96", "conv_igemm_64x160", "conv_igemm16_64x80", "conv_igemm16_64x144", "conv_igemm16_64x160",
     "stem_conv", "maxpool",
     "upsample_add", "uvd", "copy_channels", "vote", "batch_renorm", "stem_wgrad", "wgrad_fold", "eltwise_bwd", "loss", "adam",
-    "conv_wgrad_128", "conv_wgrad_64", "conv_wgrad_row96", "conv_wgrad_group"};
+    "conv_wgrad_128", "conv_wgrad_64", "conv_wgrad_row96", "conv_wgrad_group", "conv_wgrad16"};
 
 struct ProfRecord { rt::Event a, b; int kid; int tag; double flops; double bytes; };
 struct RegSeg;
@@ -232,7 +233,7 @@ struct dr_handle {
     // Weight gradients of the full-resolution layers on a library-owned low-priority stream (default; DR_WGRAD_STREAM=0 off): they are
     // needed only by the slab fold at the end of the sweep, so they are queued while the sweep runs the heads of a stack and
     // released when it enters the hourglass below -- a ~1.4 ms chain of launches too small to fill the chip.
-    struct PendingWgrad { dr::WgradParams p; int kind; int grid; };   // kind: 0 <64>, 1 <128>, 2 row kernel, 3 / 4 bf16 <64> / <128>
+    struct PendingWgrad { dr::WgradParams p; int kind; int grid; };   // kind: 0 <64>, 1 <128>, 2 row kernel, 3 / 4 bf16 <64> / <128>, 16 + id: conv_wgrad16.h
     std::vector<PendingWgrad> wg_pending;
     hipStream_t wg_stream = nullptr;
     dr::rt::Event wg_ready{}, wg_done{};

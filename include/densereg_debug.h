@@ -20,11 +20,12 @@ int dr_dbg_conv2d(int B, int H, int W, int Cin, int Cout, int k, const float* x,
 
 /* Weight gradient of one conv on caller buffers (device pointers, NHWC with row strides x_cs / g_cs):
  * dw[k][k][Cin][Cout] = sum over pixels of x(shifted by the tap, zero outside the image or where
- * rowmask[pixel] < thresh) * g.  T = 64 or 128 picks the channel tile, nsplit the pixel-axis slabs. */
+ * rowmask[pixel] < thresh) * g.  T = 64 or 128 picks the channel tile (96: the kernel-row variant; 160 + id: a 16x16-tile kernel of
+ * conv_wgrad16.h -- 161 / 162 need k = 3, 163..165 k = 1), nsplit the pixel-axis slabs. */
 int dr_dbg_wgrad(int B, int H, int W, int Cin, int Cout, int k, const float* x, int x_cs, const float* g, int g_cs,
                  const float* rowmask, float thresh, int T, int nsplit, float* dw, dr_stream stream);
 
-/* Micro-benchmark of the weight-gradient kernel + slab fold: microseconds per call for channel tile T (0 = planner's)
+/* Micro-benchmark of the weight-gradient kernel + slab fold: microseconds per call for channel tile T (0 = planner's, 160 + id as above)
  * and nsplit slabs (0 = planner's; *nsplit_used reports the count actually run). */
 int dr_dbg_wgrad_bench(int B, int H, int W, int Cin, int Cout, int k, int T, int nsplit, int iters, float* us_out,
                        int* nsplit_used);

@@ -534,6 +534,27 @@ WGRAD_CASES = [
     (1, 16, 16, 65, 96, 3, 96, 8, True),
     (2, 9, 7, 80, 70, 3, 96, 3, False),
     (1, 2, 2, 96, 65, 3, 96, 1, False),
+    # 16x16-tile kernels (conv_wgrad16.h), T = 160 + id: 1 kernel row 80x80, 2 kernel row 32x32, 3 <= 80 inputs x 128-blocks of
+    # outputs, 4 160-blocks of inputs x <= 80 outputs, 5 64x64 blocks
+    (2, 8, 8, 78, 78, 3, 161, 2, False),
+    (1, 16, 16, 65, 80, 3, 161, 8, True),
+    (2, 9, 7, 70, 66, 3, 161, 3, False),
+    (1, 2, 2, 80, 65, 3, 161, 1, False),
+    (1, 8, 8, 100, 90, 3, 161, 2, False),       # more than one channel block on both sides
+    (2, 16, 16, 16, 16, 3, 162, 4, False),
+    (1, 9, 7, 32, 19, 3, 162, 2, True),
+    (1, 8, 8, 40, 33, 3, 162, 1, False),
+    (2, 8, 8, 78, 256, 1, 163, 3, False),
+    (1, 16, 16, 65, 128, 1, 163, 8, True),
+    (1, 5, 7, 70, 131, 1, 163, 2, False),
+    (1, 4, 4, 90, 40, 1, 163, 1, False),
+    (2, 8, 8, 156, 78, 1, 164, 2, False),
+    (1, 16, 16, 131, 65, 1, 164, 16, True),
+    (1, 6, 5, 170, 85, 1, 164, 3, False),
+    (2, 16, 16, 32, 16, 1, 165, 4, False),
+    (1, 8, 8, 16, 64, 1, 165, 2, True),
+    (1, 9, 7, 32, 128, 1, 165, 3, False),
+    (1, 4, 4, 70, 14, 1, 165, 1, False),
 ]
 
 
@@ -569,6 +590,7 @@ def test_wgrad_seeded_shape_sweep(be):
         Cin = int(rng.choice([3, 16, 19, 33, 64, 70, 96, 131]))
         Cout = int(rng.choice([5, 14, 32, 42, 65, 78, 96, 128, 131]))
         Ts = [64, 128] + ([96] if (k == 3 and 64 < Cin <= 96 and 64 < Cout <= 96) else [])    # the kernel-row variant serves 65..96 channels
+        Ts += [161, 162] if k == 3 else [163, 164, 165]                                        # the 16x16-tile kernels take any channel counts
         T = int(rng.choice(Ts))
         nsplit = int(rng.integers(1, 9))
         masked = bool(rng.random() < 0.3)

@@ -81,6 +81,7 @@ SIGNATURES = {
     'dr_read_activation': (_i, [_vp, C.c_char_p, _i, _fp, _sz]),
     'dr_conv_flops_per_crop': (C.c_double, [_vp]),
     'dr_set_precision': (_i, [_vp, _i]),
+    'dr_set_fusion': (_i, [_vp, _i]),
     'dr_png_unfilter': (_i, [_vp, _i, _i, _i, _vp]),
     'dr_depth_from_samples': (_i, [_vp, C.c_long, _i, _vp, _vp]),
     'dr_flat_adam': (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]),

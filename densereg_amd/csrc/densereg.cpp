@@ -423,13 +423,24 @@ struct Builder {
         const int parent = cur_lane;
         const int child = std::min(parent + 1, DR_MAX_LANES - 1);
         const bool split = child != parent;
+        const int pool_op = (int)h->ops.size();
         TView lower1 = pool(ins, h->cfg.kernel_size);
         if (split) edge(OP_FORK, parent, child);
         TView upper1 = residual(ins, 0);
         cur_lane = child;
+        const int first_op = (int)h->ops.size();
         lower1 = residual(lower1, 0);
         TView lower2 = n > 1 ? hourglass(lower1, n - 1) : lower1;
         TView lower3 = residual(lower2, 0);
+        if (ins.t->H == 16 && ins.t->W == 16 && n == 3) {      // everything at 8x8 and below: one launch in eval mode (hg_fused.h)
+            FusedRegion fr;
+            fr.pool_op = pool_op; fr.first_op = first_op; fr.last_op = (int)h->ops.size() - 1;
+            fr.in = ins; fr.out = lower3;
+            int nc = 0;
+            for (int i = first_op; i <= fr.last_op; ++i)
+                if (h->ops[i].kind == OP_CONV && nc < 24) fr.conv[nc++] = h->ops[i].conv;
+            if (nc == 24) h->fused.push_back(fr);
+        }
         cur_lane = parent;
         if (split) edge(OP_JOIN, parent, child);
         h->n_lanes = std::max(h->n_lanes, child + 1);
@@ -673,6 +684,8 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         // other instead of side by side); with a normal-priority stream created first -- or a normal-priority side stream, which
         // measures the same 2050 -- the effect is gone (profiles/r03_experiments.md, visit 18).
         h->cap_stream = rt::stream_create();
+        const char* ft = getenv("DR_FUSE_TAIL");
+        h->fuse_tail = !(ft && ft[0] == '0');
         const char* fuse = getenv("DR_FUSE_BN_BWD");
         h->fuse_bn_bwd = !(fuse && fuse[0] == '0');
         const char* grp = getenv("DR_GROUP_WGRAD");
@@ -961,6 +974,16 @@ int dr_set_precision(dr_handle* h, int precision) {
     return DR_OK;
 }
 
+int dr_set_fusion(dr_handle* h, int on) {
+    if (!h) return DR_E_INVALID;
+    if ((on != 0) != h->fuse_tail) {
+        for (auto& g : h->graphs) rt::graph_destroy(g.g);                       // recorded launches name the other set of kernels
+        h->graphs.clear();
+    }
+    h->fuse_tail = on != 0;
+    return DR_OK;
+}
+
 int dr_finalize_params(dr_handle* h, dr_stream stream) {
     if (!h) return DR_E_INVALID;
     DR_ENTER(h);
@@ -1147,6 +1170,32 @@ static int run_simple_op(dr_handle* h, const Op& op, int B, hipStream_t s, bool 
     return DR_OK;
 }
 
+// the bottom of an hourglass as one launch (hg_fused.h)
+static int run_fused_region(dr_handle* h, const FusedRegion& fr, int B, hipStream_t s) {
+    HgFusedParams p{};
+    p.x = fr.in.t->p; p.x_cs = fr.in.t->cs; p.x_coff = fr.in.coff;
+    p.y = fr.out.t->p; p.y_cs = fr.out.t->cs; p.y_coff = fr.out.coff;
+    p.B = B; p.F = fr.in.C;
+    double flops = 0;
+    for (int i = 0; i < 24; ++i) {
+        const ConvLayer& c = h->convs[fr.conv[i]];
+        p.conv[i].w = h->wp + c.wp_off; p.conv[i].Np = c.Np;
+        p.conv[i].scale = h->fold + c.fold_off; p.conv[i].shift = h->fold + c.fold_off + c.cout;
+        flops += 2.0 * B * c.H * c.W * c.k * c.k * c.cin * c.cout;
+    }
+    const size_t lds = (size_t)hg_fused_lds_floats(p.F) * sizeof(float);
+    static const bool lds_ok = rt::allow_dyn_lds((const void*)hg_tail_eval_kernel, (size_t)hg_fused_lds_floats(128) * sizeof(float));
+    if (!lds_ok) DR_FAIL(h, DR_E_DEVICE, "fused hourglass bottom: %zu bytes of LDS per workgroup refused", lds);
+    ProfScope ps(h, s, KID_HG_FUSED, flops, 4.0 * B * p.F * (256.0 + 64.0));
+    DR_LAUNCH(hg_tail_eval_kernel, dim3(B), dim3(256), lds, s, p);
+    return DR_OK;
+}
+
+static bool fused_tail_usable(const dr_handle* h) {
+    return h->fuse_tail && !h->fused.empty() && !h->multi_stream && h->precision == 0 && hg_fused_supported(h->cfg.num_fea) &&
+           h->cfg.kernel_size == 3;
+}
+
 static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s) {
     if (!h->finalized) DR_FAIL(h, DR_E_STATE, "forward before dr_finalize_params");
     pipeline_drain(h);                                       // (training handle with two micro-step slots: the bound slot's buffers are reused)
@@ -1159,7 +1208,23 @@ static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s
         if (rc) return rc;
         h->fold_is_eval = true;
     }
-    for (const Op& op : h->ops) {
+    const bool fuse = fused_tail_usable(h);
+    size_t next_region = 0;                                  // regions are disjoint and in op order
+    for (int i = 0; i < (int)h->ops.size(); ++i) {
+        const Op& op = h->ops[i];
+        if (fuse && next_region < h->fused.size()) {
+            const FusedRegion& fr = h->fused[next_region];
+            if (i == fr.pool_op) {                           // the pool and everything in [first_op, last_op]: one launch, here
+                h->prof_tag = -1;
+                int rc = run_fused_region(h, fr, B, s);
+                if (rc) return rc;
+                continue;
+            }
+            if (i >= fr.first_op && i <= fr.last_op) {
+                if (i == fr.last_op) ++next_region;
+                continue;
+            }
+        }
         if (op.kind == OP_FORK || op.kind == OP_JOIN) { lane_edge(h, op, op.kind == OP_FORK, s); continue; }
         h->prof_tag = op.conv;
         hipStream_t ls = lane_of(h, op.lane, s);
@@ -1169,6 +1234,7 @@ static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s
     h->prof_tag = -1;
     DR_CHECK_LAUNCH(h);
     h->last_forward_train = false;
+    h->last_eval_fused = fuse;
     h->last_B = B;
     return DR_OK;
 }
@@ -1290,8 +1356,13 @@ int dr_infer(dr_handle* h, int B, const float* dm, const float* cfg, const float
 int dr_read_activation(dr_handle* h, const char* scope, int B, float* host, size_t count) {
     if (!h || !scope || !host) return DR_E_INVALID;
     pipeline_drain(h);
-    for (const Op& op : h->ops) {
+    for (size_t oi = 0; oi < h->ops.size(); ++oi) {
+        const Op& op = h->ops[oi];
         if ((op.kind != OP_CONV && op.kind != OP_STEM) || h->convs[op.conv].name != scope) continue;
+        if (!h->last_forward_train && h->last_eval_fused)
+            for (const FusedRegion& fr : h->fused)
+                if ((int)oi >= fr.first_op && (int)oi < fr.last_op)          // (the region's last conv IS written: its output tensor)
+                    DR_FAIL(h, DR_E_STATE, "dr_read_activation: %s lives only in LDS when the hourglass bottom runs as one launch; dr_set_fusion(h, 0) keeps every layer's output", scope);
         const Tensor* t = op.out.t;
         const long M = (long)B * t->H * t->W;
         const size_t need = (size_t)M * op.out.C;

@@ -45,6 +45,7 @@ inline bool capture_begin(hipStream_t) { return false; }
 inline bool capture_end(hipStream_t, Graph*) { return false; }
 inline bool graph_launch(Graph, hipStream_t) { return false; }
 inline void graph_destroy(Graph) {}
+inline bool allow_dyn_lds(const void*, size_t) { return true; }
 }}  // namespace dr::rt
 #else
 // ---------------------------------------------------------------------------------------------
@@ -112,6 +113,11 @@ inline bool capture_end(hipStream_t s, Graph* g) {
 }
 inline bool graph_launch(Graph g, hipStream_t s) { return hipGraphLaunch(g.exec, s) == hipSuccess; }
 inline void graph_destroy(Graph g) { if (g.exec) (void)hipGraphExecDestroy(g.exec); }
+// a kernel that asks for more than 64 KB of dynamic LDS per workgroup (gfx950 has 160 KB per CU) must be given the attribute once
+inline bool allow_dyn_lds(const void* kernel, size_t bytes) {
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return true;
+}
 }}  // namespace dr::rt
 #endif
 

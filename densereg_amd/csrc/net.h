@@ -9,6 +9,7 @@
 #include "dr_platform.h"
 #include "conv_wgrad.h"
 #include "conv_wgrad16.h"
+#include "hg_fused.h"
 #include "kernels_misc.h"
 
 namespace dr {
@@ -111,7 +112,7 @@ struct ParamInfo {
 
 enum KernelId {
     KID_CONV_128x128, KID_CONV_64x128, KID_CONV_128x64, KID_CONV_64x64, KID_CONV_128x32, KID_CONV_64x64_K64, KID_CONV_SPLITK, KID_CONV_64x96, KID_CONV_64x160, KID_CONV16_64x80, KID_CONV16_64x144, KID_CONV16_64x160, KID_STEM, KID_POOL, KID_UPADD, KID_UVD, KID_COPY,
-    KID_VOTE, KID_BN, KID_WGRAD, KID_WGRAD_FOLD, KID_ELTWISE, KID_LOSS, KID_ADAM,
+    KID_HG_FUSED, KID_VOTE, KID_BN, KID_WGRAD, KID_WGRAD_FOLD, KID_ELTWISE, KID_LOSS, KID_ADAM,
     KID_WGRAD_128, KID_WGRAD_64, KID_WGRAD_ROW, KID_WGRAD_GROUP, KID_WGRAD_16,   // one row per weight-gradient kernel template (KID_WGRAD: the stem's)
     KID_COUNT
 };
@@ -119,8 +120,12 @@ static const char* const kKernelNames[KID_COUNT] = {
     "conv_igemm_128x128", "conv_igemm_64x128", "conv_igemm_128x64", "conv_igemm_64x64", "conv_igemm_128x32", "conv_igemm_64x64k64", "conv_splitk_32x32",
     "conv_igemm_64x96", "conv_igemm_64x160", "conv_igemm16_64x80", "conv_igemm16_64x144", "conv_igemm16_64x160",
     "stem_conv", "maxpool",
-    "upsample_add", "uvd", "copy_channels", "vote", "batch_renorm", "stem_wgrad", "wgrad_fold", "eltwise_bwd", "loss", "adam",
+    "upsample_add", "uvd", "copy_channels", "hourglass_tail_fused", "vote", "batch_renorm", "stem_wgrad", "wgrad_fold", "eltwise_bwd", "loss", "adam",
     "conv_wgrad_128", "conv_wgrad_64", "conv_wgrad_row96", "conv_wgrad_group", "conv_wgrad16"};
+
+// The part of one hourglass below 16x16 pixels (hg_fused.h): in eval mode the ops [first_op, last_op] and the pool at pool_op are
+// ONE launch.  conv[]: the ConvLayer indices of its eight residual modules in execution order.
+struct FusedRegion { int pool_op = -1, first_op = -1, last_op = -1; TView in, out; int conv[24]; };
 
 struct ProfRecord { rt::Event a, b; int kid; int tag; double flops; double bytes; };
 struct RegSeg;
@@ -185,6 +190,9 @@ struct dr_handle {
     hipStream_t cap_stream = nullptr;                      // library-owned stream the captures are recorded on
     bool use_graphs = false;
     int precision = 0;                                      // dr_set_precision: 0 = fp32 MFMA, 1 = bf16 MFMA (inference handles)
+    std::vector<dr::FusedRegion> fused;                     // one per stack (graph builder); used by the eval forward when fuse_tail
+    bool fuse_tail = true;                                  // dr_set_fusion / DR_FUSE_TAIL=0: every op of the hourglass bottoms launches on its own
+    bool last_eval_fused = false;                           // the last eval forward skipped the fused regions' intermediate tensors
     bool fuse_bn_bwd = true;                               // DR_FUSE_BN_BWD=0: every BatchReNorm layer runs its own reduce pass
     bool multi_stream = false;                             // DR_MULTI_STREAM=1 turns the lanes on; off or profiling: every lane = caller's stream
     float* tiny = nullptr;                                  // (B,h,w) normalised depth at map resolution

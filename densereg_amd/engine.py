@@ -81,6 +81,11 @@ class Engine:
         the handle and the packed weights follow the precision)."""
         self.h.call('dr_set_precision', {'f32': 0, 'bf16': 1}[precision])
 
+    def set_fusion(self, on: bool):
+        """Eval mode: the part of every hourglass below 16x16 pixels as one launch (``dr_set_fusion``; on by default).  Off keeps
+        every layer's output in HBM (``read_activation``)."""
+        self.h.call('dr_set_fusion', 1 if on else 0)
+
     def load_params(self, params: Dict[str, np.ndarray]):
         self.h.load_params(params)
         self.h.call('dr_finalize_params', self._stream())

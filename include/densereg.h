@@ -206,6 +206,13 @@ int dr_depth_from_samples(const uint8_t* samples_dev, long npix, int mode, float
 #define DR_PREC_BF16 1
 int dr_set_precision(dr_handle* h, int precision);
 
+/* ---- eval-mode fusion ---------------------------------------------------------------------------- */
+/* In eval mode (dr_forward_eval / dr_infer, fp32 matrix cores, num_fea a multiple of 32 up to 128) the part of every hourglass
+ * below 16x16 pixels -- 24 convolutions, 3 pools, 2 upsample-adds of network/um_v1.py:51-69 -- runs as ONE launch with its
+ * intermediate tensors in LDS (on by default; same results up to fp32 summation order).  on = 0 launches every op on its own, which
+ * also keeps every layer's output in HBM for dr_read_activation. */
+int dr_set_fusion(dr_handle* h, int on);
+
 /* ---- introspection (tests / profiling) ----------------------------------------------------------- */
 /* Post-activation output of conv `scope` (e.g. "Conv_12") of the last forward as dense NHWC. */
 int dr_read_activation(dr_handle* h, const char* scope, int B, float* host, size_t count);

@@ -345,6 +345,15 @@ def test_network_forward_and_vote_config1(be, case1):
     assert np.abs(hm[:, ::2, ::2] - g['hm']).max() < 2e-4
     assert np.abs(hm3[:, ::2, ::2] - g['hm3']).max() < 2e-4
     assert np.abs(um[:, ::2, ::2] - g['um']).max() < 2e-4
+    # (that forward ran the hourglass bottom as ONE launch, hg_fused.h; with the fusion off every layer's output stays in HBM --
+    # and the two forwards agree to fp32 summation order)
+    from densereg_amd._lib import DenseRegError
+    with pytest.raises(DenseRegError):
+        be.read_activation(h, 'Conv_10', (1, 8, 8, 32))             # lower1 @8x8, 3x3: lives only in LDS
+    h.call('dr_set_fusion', 0)
+    hm_u, hm3_u, um_u = be.forward_eval(h, ndm)
+    for a_f, a_u in ((hm, hm_u), (hm3, hm3_u), (um, um_u)):
+        assert np.abs(a_f - a_u).max() <= 2e-5 * max(1.0, float(np.abs(a_u).max()))
     # every conv output against the oracle's record
     rec = {}
     net.forward_eval(cfg, params, ndm, record=rec)
@@ -358,6 +367,7 @@ def test_network_forward_and_vote_config1(be, case1):
     xyz = be.vote(h, hm, hm3, um, ndm, cfgs, coms)
     ref_same = pose.estimate_pose_mm(hm, hm3, um, ndm, cfgs, coms)
     assert np.abs(xyz - ref_same).max() < 1e-3
+    h.call('dr_set_fusion', 1)
     xyz2 = be.infer(h, ndm, cfgs, coms)
     assert pose.mean_jnt_error(xyz2, g['xyz']) <= 0.1           # BASELINE.json tolerance
     assert np.abs(xyz2 - g['xyz']).max() < 0.05

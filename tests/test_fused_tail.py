@@ -1,0 +1,111 @@
+"""The bottom of every hourglass (8x8 pixels and below: 24 convolutions, 3 pools, 2 upsample-adds of network/um_v1.py:51-69) as ONE
+launch in eval mode (``densereg_amd/csrc/hg_fused.h``, ``dr_set_fusion``): against the unfused executor (same arithmetic, other
+summation order: 2e-5 of a map's range), against the oracle, per crop independent of the batch, on handles it does not apply to
+(F not a multiple of 32: silently the unfused path), and on a training handle's eval forward.  ``[emu]`` on CPU fibers, ``[gpu]``
+on an MI355X."""
+import numpy as np
+import pytest
+
+BACKENDS = [pytest.param('emu'), pytest.param('gpu', marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def be(request):
+    return request.getfixturevalue(request.param)
+
+
+def _case(S, F, J, B, seed=31):
+    from densereg_amd.data.synthetic import make_crops
+    from oracle import net, pose
+    from oracle.graph import NetConfig
+    cfg = NetConfig(S, F, J)
+    dm, poses, cfgs, coms, _ = make_crops(B, 'icvl', seed=seed)
+    ndm = pose.norm_dm(dm, coms)
+    params = net.make_test_params(cfg, ndm[:2], seed=5)
+    return cfg, params, ndm, cfgs, coms
+
+
+def _close(a, b, tol=2e-5):
+    return np.abs(a - b).max() <= tol * max(1.0, float(np.abs(b).max()))
+
+
+@pytest.mark.parametrize('F', [32, 96])
+def test_fused_tail_matches_unfused_and_oracle(be, F):
+    """F = 32: one column tile for two of the four waves; F = 96: three 16-column tiles of the half-width layers, six of the full."""
+    from oracle import net
+    if be.name == 'emu' and F == 96:
+        pytest.skip('F = 96 on CPU fibers is minutes; covered on the GPU')
+    S, J, B = 1, 3, 2 if be.name == 'emu' else 5
+    cfg, params, ndm, cfgs, coms = _case(S, F, J, B)
+    h = be.handle(cfg, B)
+    h.load_params(params)
+    h.call('dr_finalize_params', be.stream)
+    fused = be.forward_eval(h, ndm)
+    xyz_f = be.infer(h, ndm, cfgs, coms)
+    h.call('dr_set_fusion', 0)
+    plain = be.forward_eval(h, ndm)
+    xyz_p = be.infer(h, ndm, cfgs, coms)
+    ep = net.forward_eval(cfg, params, ndm)
+    for a, b, key in zip(fused, plain, ('hm_outs', 'hm3_outs', 'um_outs')):
+        assert _close(a, b), key
+        assert np.abs(a - ep[key][-1]).max() < 5e-4 * max(1.0, float(np.abs(ep[key][-1]).max())), key
+    assert np.isfinite(xyz_f).all() and xyz_f.shape == xyz_p.shape
+    # per crop the fused launch does not depend on the batch around it: a single crop gives the same bits
+    h.call('dr_set_fusion', 1)
+    one = be.forward_eval(h, np.ascontiguousarray(ndm[1:2]))
+    again = be.forward_eval(h, ndm)
+    for a, b, c in zip(one, fused, again):
+        np.testing.assert_array_equal(b, c)                       # run to run
+    if be.name == 'gpu':
+        # (the layers around the fused part pick their tiles by batch size, so single-crop bit equality is a statement about
+        # the whole forward only where those agree: B = 5 and B = 1 both run the small-grid tiles at this size)
+        for a, b in zip(one, fused):
+            assert _close(a[0], b[1])
+    h.close()
+
+
+def test_fusion_flag_is_harmless_where_it_does_not_apply(be):
+    """F = 8: not a multiple of 32 -- dr_set_fusion(1) changes nothing, every layer stays readable."""
+    cfg, params, ndm, cfgs, coms = _case(1, 8, 2, 1)
+    h = be.handle(cfg, 1)
+    h.load_params(params)
+    h.call('dr_finalize_params', be.stream)
+    h.call('dr_set_fusion', 1)
+    a = be.forward_eval(h, ndm)
+    act = be.read_activation(h, 'Conv_10', (1, 8, 8, 4))
+    h.call('dr_set_fusion', 0)
+    b = be.forward_eval(h, ndm)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(act, be.read_activation(h, 'Conv_10', (1, 8, 8, 4)))
+    h.close()
+
+
+@pytest.mark.gpu
+def test_fused_tail_config2_b40_and_training_handle(gpu):
+    """BASELINE config 2's shape (ICVL S=2 F=128 B=40): fused against unfused on every head map of both stacks' outputs and on the
+    voted joints; the eval forward of a TRAINING handle (its fold buffer holds train-step values until an eval pass refolds it)
+    takes the same path."""
+    import ctypes as C
+    be = gpu
+    cfg, params, ndm, cfgs, coms = _case(2, 128, 16, 40, seed=20240)
+    for training in (False, True):
+        h = be.handle(cfg, 40, training=training)
+        h.load_params(params)
+        h.call('dr_finalize_params', be.stream)
+        if training:                                              # a training forward in between: scale | shift now hold batch values
+            d = be.dev(ndm)
+            h.call('dr_forward_train', 40, be.ptr(d), 0, None, C.c_uint64(0), be.stream)
+            be.sync()
+            h.load_params(params)                                 # (the moving statistics moved: restore, refold)
+            h.call('dr_finalize_params', be.stream)
+        fused = be.forward_eval(h, ndm)
+        xyz_f = be.infer(h, ndm, cfgs, coms)
+        h.call('dr_set_fusion', 0)
+        plain = be.forward_eval(h, ndm)
+        xyz_p = be.infer(h, ndm, cfgs, coms)
+        for a, b in zip(fused, plain):
+            assert _close(a, b)
+        d = np.linalg.norm((xyz_f - xyz_p).reshape(-1, 3), axis=1)
+        assert np.quantile(d, 0.98) < 5e-3 and (d > 0.1).sum() <= 0.01 * d.size, (np.quantile(d, 0.98), (d > 0.1).sum())
+        h.close()

@@ -71,6 +71,7 @@ def test_config4_msra_j21_forward_b40(gpu):
     from oracle import net
     from oracle.graph import conv_specs
     sub = np.ascontiguousarray(ndm[:2])
+    h.call('dr_set_fusion', 0)                          # every layer's output in HBM (the B=40 pass above ran the fused hourglass bottoms)
     gpu.forward_eval(h, sub)
     rec = {}
     net.forward_eval(cfg, params, sub, record=rec)

@@ -101,6 +101,7 @@ def test_every_layer_config2_small_batch(gpu, config2):
     from oracle.graph import conv_specs
     c = config2
     ndm = np.ascontiguousarray(c['ndm'][:2])
+    c['h'].call('dr_set_fusion', 0)                     # every layer's output in HBM
     gpu.forward_eval(c['h'], ndm)
     rec = {}
     net.forward_eval(c['cfg'], c['params'], ndm, record=rec)
@@ -108,6 +109,7 @@ def test_every_layer_config2_small_batch(gpu, config2):
         a = gpu.read_activation(c['h'], cs.name, (2, cs.h_out, cs.w_out, cs.cout))
         r = rec.get(cs.name + '+res', rec[cs.name])
         assert np.abs(a - r).max() / (np.abs(r).max() + 1e-12) < 2e-4, cs.name
+    c['h'].call('dr_set_fusion', 1)
 
 
 def test_input_256_maps_64_forward_and_vote(gpu):

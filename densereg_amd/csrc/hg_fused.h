@@ -23,6 +23,11 @@
 // Activation fragments come from the LDS image [pixel][channel] (row stride C + 4 floats: an odd number of 16-byte slots, so
 // the 16 rows of a ds_read_b128 lane group fall on different banks); a 3x3 tap outside the image reads a row of zeros.
 // With one row tile (4x4, 2x2) the four MFMA steps of a K-group feed four independent accumulators (summed in a fixed order).
+//
+// Measured on MI355X (profiles/r04_experiments.md section 4), ICVL S=2 F=128: the launch takes 110 us at 40 crops (92 us for one
+// crop) and replaces 29 launches of 6.6 us each; forward + vote B=1 1.144 -> 0.996 ms, B=40 7880 -> 8150 crops/s on one engine.
+// 3536 MFMAs per wave are ~50 us of issue; the rest is the single-row-tile levels (a group is 4 MFMAs: LDS and L2 round trips show),
+// ~21 us of weight fetches that do not hide at 40 workgroups, ~5 us of barriers.  Four and eight waves per workgroup measure equal.
 #pragma once
 #include "dr_platform.h"
 #include "kernels_misc.h"
@@ -44,23 +49,37 @@ __host__ __device__ inline int hg_fused_lds_floats(int F) {
 }
 inline bool hg_fused_supported(int F) { return F >= 32 && F % 32 == 0 && F <= 128; }
 
-// 3x3 / stride 2 max pool, TF 'SAME' on an even side: window rows 2oy .. 2oy+2 clipped to the image (padding never wins)
+// 3x3 / stride 2 max pool, TF 'SAME' on an even side: window rows 2oy .. 2oy+2 clipped to the image (padding never wins).  The
+// clip is a CLAMP of the index -- a duplicate cannot change a maximum -- so the nine loads of an output element are unconditional
+// and independent: behind "if (iy >= side) continue" they were issued one at a time, and the first pool reads HBM (72 dependent
+// round trips per thread = a third of the launch).
 __device__ __forceinline__ void hg_pool(const float* src, int s_stride, int side_in, float* dst, int d_stride, int C) {
-    const int so = side_in >> 1, c4n = C >> 2;
-    for (int i = threadIdx.x; i < so * so * c4n; i += blockDim.x) {
-        const int c4 = i % c4n, px = i / c4n, ox = px % so, oy = px / so;
-        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = 2 * oy + ky;
-            if (iy >= side_in) continue;
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = 2 * ox + kx;
-                if (ix >= side_in) continue;
-                const float4 v = *reinterpret_cast<const float4*>(src + (long)(iy * side_in + ix) * s_stride + c4 * 4);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    const int so = side_in >> 1, c4n = C >> 2, last = side_in - 1;
+    const int n = so * so * c4n;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 2 * blockDim.x) {
+        float4 v[2][9];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + u * blockDim.x < n ? i0 + u * blockDim.x : i0;     // (a thread past the end re-reads its first element)
+            const int c4 = i % c4n, px = i / c4n, ox = px % so, oy = px / so;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ry = 2 * oy + t / 3, rx = 2 * ox + t % 3;
+                const int iy = ry < last ? ry : last, ix = rx < last ? rx : last;
+                v[u][t] = *reinterpret_cast<const float4*>(src + (long)(iy * side_in + ix) * s_stride + c4 * 4);
             }
         }
-        *reinterpret_cast<float4*>(dst + px * d_stride + c4 * 4) = m;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i >= n) break;
+            float4 m = v[u][0];
+#pragma unroll
+            for (int t = 1; t < 9; ++t) {
+                m.x = fmaxf(m.x, v[u][t].x); m.y = fmaxf(m.y, v[u][t].y); m.z = fmaxf(m.z, v[u][t].z); m.w = fmaxf(m.w, v[u][t].w);
+            }
+            *reinterpret_cast<float4*>(dst + (i / c4n) * d_stride + (i % c4n) * 4) = m;
+        }
     }
 }
 
@@ -77,158 +96,250 @@ __device__ __forceinline__ void hg_upadd(float* dst, int side, const float* lo, 
     }
 }
 
-// One convolution + folded BatchReNorm + ReLU (+ in-place skip) on an LDS-resident crop.  RT4: 64 pixels = four 16-row tiles;
-// otherwise one row tile (M = 16 or 4 live rows) and the four steps of a K-group accumulate into four independent tiles.
-// src [M][Cin] (row stride s_stride) -> dst [M][Cout] (row stride d_stride); add_dst: dst += (the residual skip, in place);
-// gout != null: the result goes to HBM (row stride g_stride) instead of dst.
-template <bool RT4>
-__device__ __forceinline__ void hg_conv(const float* src, int s_stride, int Cin, int side, int M, int ksize, const HgConvDesc& d, int Cout,
-                                        float* dst, int d_stride, bool add_dst, float* gout, int g_stride, const float* zrow) {
-    constexpr int NRT = RT4 ? 4 : 1;               // row tiles
-    constexpr int QC = 2;                          // column tiles per wave (Cout <= 128)
-    constexpr int GB = 4;                          // K-groups whose weight fragments are fetched as one batch, one batch ahead
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// ---- the convolutions ---------------------------------------------------------------------------------------------------
+// Everything that shapes the code is a compile-time constant (F, the convolution's position in the residual module, four row
+// tiles or one), so every register array is indexed statically and the K loops unroll: an earlier version with run-time shapes
+// spent more instructions on tap predicates, integer divisions and accumulator moves than on MFMAs, and one that inlined all 24
+// convolutions was 145 KB of code executed once (the kernel waited for its own instruction fetches).  The kernel is a run-time
+// LOOP over the eight residual modules; its body holds the six convolution bodies {1x1 in, 3x3, 1x1 out} x {four row tiles, one}.
+//
+// Weights: a lane's fragment of K-group (chunk, tap) and column tile ct is the 16 bytes at packed[(chunk * taps + tap) * Np + n] *
+// 16 + 4 g, n = 16 ct + r.  With one wave per SIMD nothing hides an L2 round trip, so weights travel one convolution ahead: ALL
+// of a 1x1 convolution's fragments (at most 8 float4 per lane for F <= 128) are fetched while the convolution before it computes,
+// a 3x3's one 16-channel chunk (9 taps) ahead.
+struct HgW { float4 b[9]; float sc[2], sh[2]; };
+
+template <int F> struct HgShape {
+    static constexpr int H = F / 2;                // half width
+    static constexpr int sF = F + 4, sH = H + 4;   // LDS row strides (floats)
+    static constexpr int CT1 = H / 16;             // column tiles of the half-width outputs (<= 4: one per wave)
+    static constexpr int CT3 = F / 16;             // ... of the F-channel output (<= 8: up to two per wave)
+    static constexpr int QC3 = CT3 > 4 ? 2 : 1;
+    static constexpr int NG1 = F / 16;             // K-groups of the first 1x1 (Cin = F)
+    static constexpr int NC2 = H / 16;             // 16-channel chunks of the 3x3 (x 9 taps)
+    static constexpr int NG3 = H / 16;             // K-groups of the last 1x1 (Cin = F / 2)
+    static_assert(NG1 <= 9 && NG3 * QC3 <= 9 && CT1 <= 4 && CT3 <= 8, "F <= 128");
+};
+
+// which: 0 = first 1x1 (F -> F/2), 1 = 3x3 (F/2 -> F/2; chunk `chunk`), 2 = last 1x1 (F/2 -> F)
+template <int F, int WHICH>
+__device__ __forceinline__ void hg_fetch(const HgConvDesc& d, int chunk, HgW& w) {
+    using S = HgShape<F>;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     const int r = lane & 15, g = lane >> 4;
-    const int CT = Cout >> 4;
-    const int taps = ksize * ksize, pad = ksize >> 1;
-    const int NG = (Cin >> 4) * taps;              // K-groups of 16: (16-channel chunk, tap), taps innermost -- the packing order
-    const int side_shift = side == 8 ? 3 : (side == 4 ? 2 : 1);
-    // this lane's weight rows: output channel n = 16 ct + r of column tiles ct = wave, wave + 4 (clamped: a dead tile recomputes the
-    // wave's first one and is not stored)
-    int wofs[QC];
-    bool ct_ok[QC];
+    constexpr int CT = WHICH == 2 ? S::CT3 : S::CT1;
+    constexpr int QC = WHICH == 2 ? S::QC3 : 1;
 #pragma unroll
     for (int q = 0; q < QC; ++q) {
         const int ct = wave + 4 * q;
-        ct_ok[q] = ct < CT;
-        wofs[q] = ((ct_ok[q] ? ct : (wave < CT ? wave : 0)) * 16 + r) * 16 + 4 * g;
+        const int n = (ct < CT ? ct : (wave < CT ? wave : 0)) * 16 + r;     // (a dead tile re-reads a live one: never stored)
+        const float* wp = d.w + (long)n * 16 + 4 * g;
+        if (WHICH != 1 || chunk == 0) { w.sc[q] = d.scale[n]; w.sh[q] = d.shift[n]; }
+        if (WHICH == 0) {
+#pragma unroll
+            for (int gi = 0; gi < S::NG1; ++gi) w.b[gi] = *reinterpret_cast<const float4*>(wp + (long)gi * d.Np * 16);
+        } else if (WHICH == 1) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) w.b[tap] = *reinterpret_cast<const float4*>(wp + (long)(chunk * 9 + tap) * d.Np * 16);
+        } else {
+#pragma unroll
+            for (int gi = 0; gi < S::NG3; ++gi) w.b[gi * QC + q] = *reinterpret_cast<const float4*>(wp + (long)gi * d.Np * 16);
+        }
     }
-    const bool wave_live = wave < CT;
-    // this lane's pixel per row tile
-    int py[NRT], px[NRT];
-    bool p_ok[NRT];
-#pragma unroll
-    for (int t = 0; t < NRT; ++t) {
-        const int p = t * 16 + r;
-        p_ok[t] = p < M;
-        py[t] = p >> side_shift; px[t] = p & (side - 1);
-    }
-    dr_f32x4 acc[4][QC];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int q = 0; q < QC; ++q)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[a][q][v] = 0.f;
+}
 
-    float4 bn[GB][QC], bc[GB][QC];
-    auto fetch = [&](int g0) __attribute__((always_inline)) {
+// MFMAs of one K-group: a[t] = this lane's four k of row tile t, b = its four k of one column tile.  NRT > 1: one accumulator per row
+// tile; NRT == 1: the four steps go to four accumulators (a single tile would be one dependent chain), summed by the epilogue.
+template <int NRT>
+__device__ __forceinline__ void hg_mfma(const float4 (&a)[NRT], const float4 b, dr_f32x4 (&acc)[4]) {
 #pragma unroll
-        for (int j = 0; j < GB; ++j) {
-            const int gi = g0 + j < NG ? g0 + j : NG - 1;           // (a group past the end re-reads the last one: dropped below)
-#pragma unroll
-            for (int q = 0; q < QC; ++q) bn[j][q] = *reinterpret_cast<const float4*>(d.w + (long)gi * d.Np * 16 + wofs[q]);
-        }
-    };
-    if (wave_live) fetch(0);
-    for (int g0 = 0; g0 < NG; g0 += GB) {
-        if (!wave_live) break;
-#pragma unroll
-        for (int j = 0; j < GB; ++j)
-#pragma unroll
-            for (int q = 0; q < QC; ++q) bc[j][q] = bn[j][q];
-        if (g0 + GB < NG) fetch(g0 + GB);
-#pragma unroll
-        for (int j = 0; j < GB; ++j) {
-            const int gi = g0 + j;
-            if (gi >= NG) break;                                     // wave-uniform
-            const int chunk = gi / taps, tap = gi - chunk * taps;
-            const int dy = tap / ksize - pad, dx = tap - (tap / ksize) * ksize - pad;
-            float4 a[NRT];
-#pragma unroll
-            for (int t = 0; t < NRT; ++t) {
-                const int yy = py[t] + dy, xx = px[t] + dx;
-                const bool ok = p_ok[t] && yy >= 0 && yy < side && xx >= 0 && xx < side;
-                const float* ap = ok ? src + ((yy << side_shift) + xx) * s_stride : zrow;
-                a[t] = *reinterpret_cast<const float4*>(ap + chunk * 16 + 4 * g);
-            }
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                for (int t = 0; t < NRT; ++t)
-#pragma unroll
-                    for (int q = 0; q < QC; ++q) {
-                        const float av = s4 == 0 ? a[t].x : s4 == 1 ? a[t].y : s4 == 2 ? a[t].z : a[t].w;
-                        const float bv = s4 == 0 ? bc[j][q].x : s4 == 1 ? bc[j][q].y : s4 == 2 ? bc[j][q].z : bc[j][q].w;
-                        const int ai = RT4 ? t : s4;
-                        acc[ai][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[ai][q], 0, 0, 0);
-                    }
-        }
-    }
-    // epilogue: accumulator register v of a tile is (row 4 g + v, column r)
-#pragma unroll
-    for (int q = 0; q < QC; ++q) {
-        if (!ct_ok[q]) continue;
-        const int n = (wave + 4 * q) * 16 + r;
-        const float sc = d.scale[n], sh = d.shift[n];
+    for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
         for (int t = 0; t < NRT; ++t) {
-            dr_f32x4 sum = acc[RT4 ? t : 0][q];
-            if (!RT4) sum = (sum + acc[1][q]) + (acc[2][q] + acc[3][q]);
+            const float av = s4 == 0 ? a[t].x : s4 == 1 ? a[t].y : s4 == 2 ? a[t].z : a[t].w;
+            const float bv = s4 == 0 ? b.x : s4 == 1 ? b.y : s4 == 2 ? b.z : b.w;
+            const int ai = NRT > 1 ? t : s4;
+            acc[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[ai], 0, 0, 0);
+        }
+}
+
+// epilogue of one column tile: folded BatchReNorm + ReLU (+ skip, in place); accumulator register v of a tile is (row 4 g + v,
+// column r).  gout != null: to HBM instead of dst.
+template <int NRT>
+__device__ __forceinline__ void hg_epilogue(dr_f32x4 (&acc)[4], int rt0, int M, int n, float sc, float sh, float* dst, int d_stride, bool add_dst,
+                                            float* gout, int g_stride) {
+    const int g = (threadIdx.x & 63) >> 4;
+    if (NRT == 1) acc[0] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int p = t * 16 + 4 * g + v;
-                if (p >= M) continue;
-                float val = fmaxf(sum[v] * sc + sh, 0.f);
-                if (add_dst) val += dst[p * d_stride + n];
-                if (gout) gout[(long)p * g_stride + n] = val;
-                else dst[p * d_stride + n] = val;
+    for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int p = (rt0 + t) * 16 + 4 * g + v;
+            if (p >= M) continue;
+            float val = fmaxf(acc[t][v] * sc + sh, 0.f);
+            if (add_dst) val += dst[p * d_stride + n];
+            if (gout) gout[(long)p * g_stride + n] = val;
+            else dst[p * d_stride + n] = val;
+        }
+}
+
+// One residual module in place on X (side x side pixels, M = side^2 live rows).  RT4: the 8x8 level, four row tiles (NW = 8: two per
+// wave, waves 4..7 the second half); otherwise one row tile.  w1: the first convolution's weights (fetched by whoever ran before);
+// nd: the NEXT module's descriptors (its first convolution is fetched under this module's last), null at the end.
+template <int F, bool RT4, int NW>
+__device__ __forceinline__ void hg_residual(float* X, int side, int side_shift, int M, const HgConvDesc* d, float* T1, float* T2, const float* zrow,
+                                            float* gout, int g_stride, HgW& w1, const HgConvDesc* nd) {
+    using S = HgShape<F>;
+    constexpr int NRT = RT4 ? (NW == 8 ? 2 : 4) : 1;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, rh = threadIdx.x >> 8;
+    const int r = lane & 15, g = lane >> 4;
+    const int rt0 = RT4 ? rh * NRT : 0;
+    const bool rows_live = RT4 || rh == 0;
+    // this lane's pixel per row tile, and for the 3x3 the LDS offset of every tap (a tap outside the image, or a dead row: the zero row)
+    int pix[NRT];
+    bool p_ok[NRT];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) { pix[t] = (rt0 + t) * 16 + r; p_ok[t] = pix[t] < M; }
+    HgW w2, w3;
+    dr_f32x4 acc[2][4];
+
+    // ---- 1x1, F -> F/2:  X -> T1 ----------------------------------------------------------------------------------------------
+    hg_fetch<F, 1>(d[1], 0, w2);                                    // the 3x3's first chunk travels under this convolution
+    if (rows_live && wave < S::CT1) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[0][a][v] = 0.f;
+        const float* ap[NRT];
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) ap[t] = (p_ok[t] ? X + pix[t] * S::sF : zrow) + 4 * g;
+        // (the fragments of K-group gi + 1 are read before the MFMAs of group gi are issued: with one wave per SIMD an LDS round
+        // trip in front of every group was a third of the loop)
+        float4 a[2][NRT];
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) a[0][t] = *reinterpret_cast<const float4*>(ap[t]);
+#pragma unroll
+        for (int gi = 0; gi < S::NG1; ++gi) {
+            if (gi + 1 < S::NG1) {
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) a[(gi + 1) & 1][t] = *reinterpret_cast<const float4*>(ap[t] + (gi + 1) * 16);
+            }
+            hg_mfma<NRT>(a[gi & 1], w1.b[gi], acc[0]);
+        }
+        hg_epilogue<NRT>(acc[0], rt0, M, wave * 16 + r, w1.sc[0], w1.sh[0], T1, S::sH, false, nullptr, 0);
+    }
+    __syncthreads();
+    // ---- 3x3, F/2 -> F/2:  T1 -> T2 -------------------------------------------------------------------------------------------
+    {
+        const bool live = rows_live && wave < S::CT1;
+        const float* tp[NRT][9];
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) {
+            const int y = pix[t] >> side_shift, x = pix[t] & (side - 1);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                const bool ok = p_ok[t] && yy >= 0 && yy < side && xx >= 0 && xx < side;
+                tp[t][tap] = (ok ? T1 + ((yy << side_shift) + xx) * S::sH : zrow) + 4 * g;
             }
         }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[0][a][v] = 0.f;
+        HgW wn;
+        float4 a2[2][NRT];
+#pragma unroll
+        for (int c = 0; c < S::NC2; ++c) {
+            if (c + 1 < S::NC2) hg_fetch<F, 1>(d[1], c + 1, (c & 1) ? w2 : wn);     // the next chunk's nine taps, under this one's MFMAs
+            else hg_fetch<F, 2>(d[2], 0, w3);                                          // ... or the last 1x1's weights
+            const HgW& wc = (c & 1) ? wn : w2;
+            if (live) {
+                if (c == 0) {
+#pragma unroll
+                    for (int t = 0; t < NRT; ++t) a2[0][t] = *reinterpret_cast<const float4*>(tp[t][0]);
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int gi = c * 9 + tap;                    // (compile-time after unrolling: the buffer parity is static)
+                    if (gi + 1 < S::NC2 * 9) {
+                        const int nc = tap == 8 ? c + 1 : c, nt = tap == 8 ? 0 : tap + 1;
+#pragma unroll
+                        for (int t = 0; t < NRT; ++t) a2[(gi + 1) & 1][t] = *reinterpret_cast<const float4*>(tp[t][nt] + nc * 16);
+                    }
+                    hg_mfma<NRT>(a2[gi & 1], wc.b[tap], acc[0]);
+                }
+            }
+        }
+        if (live) hg_epilogue<NRT>(acc[0], rt0, M, wave * 16 + r, w2.sc[0], w2.sh[0], T2, S::sH, false, nullptr, 0);
     }
+    __syncthreads();
+    // ---- 1x1, F/2 -> F, + skip:  T2 -> X (in place) or HBM ---------------------------------------------------------------------------
+    if (nd) hg_fetch<F, 0>(nd[0], 0, w1);                           // the next module's first convolution
+    if (rows_live && wave < S::CT3) {
+#pragma unroll
+        for (int q = 0; q < S::QC3; ++q)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[q][a][v] = 0.f;
+        const float* ap[NRT];
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) ap[t] = (p_ok[t] ? T2 + pix[t] * S::sH : zrow) + 4 * g;
+        float4 a[2][NRT];
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) a[0][t] = *reinterpret_cast<const float4*>(ap[t]);
+#pragma unroll
+        for (int gi = 0; gi < S::NG3; ++gi) {
+            if (gi + 1 < S::NG3) {
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) a[(gi + 1) & 1][t] = *reinterpret_cast<const float4*>(ap[t] + (gi + 1) * 16);
+            }
+#pragma unroll
+            for (int q = 0; q < S::QC3; ++q) hg_mfma<NRT>(a[gi & 1], w3.b[gi * S::QC3 + q], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < S::QC3; ++q)
+            if (wave + 4 * q < S::CT3)
+                hg_epilogue<NRT>(acc[q], rt0, M, (wave + 4 * q) * 16 + r, w3.sc[q], w3.sh[q], X, S::sF, true, gout, g_stride);
+    }
+    __syncthreads();
 }
 
-template <bool RT4>
-__device__ __forceinline__ void hg_residual(float* buf, int sF, int F, int side, int M, const HgConvDesc* d, float* T1, float* T2, int sH,
-                                            const float* zrow, float* gout, int g_stride) {
-    hg_conv<RT4>(buf, sF, F, side, M, 1, d[0], F / 2, T1, sH, false, nullptr, 0, zrow);
-    __syncthreads();
-    hg_conv<RT4>(T1, sH, F / 2, side, M, 3, d[1], F / 2, T2, sH, false, nullptr, 0, zrow);
-    __syncthreads();
-    hg_conv<RT4>(T2, sH, F / 2, side, M, 1, d[2], F, buf, sF, true, gout, g_stride, zrow);
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256, 1) void hg_tail_eval_kernel(const HgFusedParams p) {
+template <int F, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void hg_tail_eval_kernel(const HgFusedParams p) {
+    using S = HgShape<F>;
     DR_DYN_SMEM(smem_raw);
     float* lds = reinterpret_cast<float*>(smem_raw);
-    const int F = p.F, sF = F + 4, sH = F / 2 + 4;
     float* A = lds;
-    float* T1 = A + 64 * sF;
-    float* T2 = T1 + 64 * sH;
-    float* C = T2 + 64 * sH;
-    float* D = C + 16 * sF;
-    float* Z = D + 4 * sF;
-    for (int i = threadIdx.x; i < sF; i += blockDim.x) Z[i] = 0.f;
+    float* T1 = A + 64 * S::sF;
+    float* T2 = T1 + 64 * S::sH;
+    float* C = T2 + 64 * S::sH;
+    float* D = C + 16 * S::sF;
+    float* Z = D + 4 * S::sF;
+    for (int i = threadIdx.x; i < S::sF; i += blockDim.x) Z[i] = 0.f;
     const int b = blockIdx.x;
-    hg_pool(p.x + (long)b * 256 * p.x_cs + p.x_coff, p.x_cs, 16, A, sF, F);
+    HgW w1;
+    hg_fetch<F, 0>(p.conv[0], 0, w1);                              // the first weights travel while the input is pooled
+    hg_pool(p.x + (long)b * 256 * p.x_cs + p.x_coff, p.x_cs, 16, A, S::sF, F);
     __syncthreads();
-    hg_residual<true>(A, sF, F, 8, 64, p.conv + 0, T1, T2, sH, Z, nullptr, 0);            // lower1 @8
-    hg_pool(A, sF, 8, C, sF, F);
-    __syncthreads();
-    hg_residual<true>(A, sF, F, 8, 64, p.conv + 3, T1, T2, sH, Z, nullptr, 0);            // upper1 @8
-    hg_residual<false>(C, sF, F, 4, 16, p.conv + 6, T1, T2, sH, Z, nullptr, 0);           // lower1 @4
-    hg_pool(C, sF, 4, D, sF, F);
-    __syncthreads();
-    hg_residual<false>(C, sF, F, 4, 16, p.conv + 9, T1, T2, sH, Z, nullptr, 0);           // upper1 @4
-    hg_residual<false>(D, sF, F, 2, 4, p.conv + 12, T1, T2, sH, Z, nullptr, 0);           // lower1 @2
-    hg_residual<false>(D, sF, F, 2, 4, p.conv + 15, T1, T2, sH, Z, nullptr, 0);           // lower3 @2
-    hg_upadd(C, 4, D, sF, F);
-    __syncthreads();
-    hg_residual<false>(C, sF, F, 4, 16, p.conv + 18, T1, T2, sH, Z, nullptr, 0);          // lower3 @4
-    hg_upadd(A, 8, C, sF, F);
-    __syncthreads();
-    hg_residual<true>(A, sF, F, 8, 64, p.conv + 21, T1, T2, sH, Z, p.y + (long)b * 64 * p.y_cs + p.y_coff, p.y_cs);   // lower3 @8 -> HBM
+    // the eight residual modules of the header comment; what happens in front of module r: 1 C = pool(A), 3 D = pool(C), 6 C += up(D),
+    // 7 A += up(C)
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < 8; ++r) {
+        if (r == 1) { hg_pool(A, S::sF, 8, C, S::sF, F); __syncthreads(); }
+        else if (r == 3) { hg_pool(C, S::sF, 4, D, S::sF, F); __syncthreads(); }
+        else if (r == 6) { hg_upadd(C, 4, D, S::sF, F); __syncthreads(); }
+        else if (r == 7) { hg_upadd(A, 8, C, S::sF, F); __syncthreads(); }
+        const HgConvDesc* d = p.conv + 3 * r;
+        const HgConvDesc* nd = r < 7 ? d + 3 : nullptr;
+        if (r <= 1 || r == 7) {
+            hg_residual<F, true, NW>(A, 8, 3, 64, d, T1, T2, Z, r == 7 ? p.y + (long)b * 64 * p.y_cs + p.y_coff : nullptr, p.y_cs, w1, nd);
+        } else {
+            const bool four = r == 2 || r == 3 || r == 6;            // 4x4 on C, else 2x2 on D
+            hg_residual<F, false, NW>(four ? C : D, four ? 4 : 2, four ? 2 : 1, four ? 16 : 4, d, T1, T2, Z, nullptr, 0, w1, nd);
+        }
+    }
 }
 
 }  // namespace dr

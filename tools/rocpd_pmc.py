@@ -55,8 +55,12 @@ def short_name(n):
     m = re.search(r'conv_wgrad(?:_bf16|_tr)?_kernel<(\d+)', n)
     if m:
         return 'conv_wgrad_%s' % m.group(1)
+    if 'conv_wgrad16_kernel' in n:
+        return 'conv_wgrad16'
     if 'stem_wgrad_kernel' in n:
         return 'stem_wgrad'
+    if 'hg_tail_eval_kernel' in n:
+        return 'hourglass_tail_fused'
     return None
 
 

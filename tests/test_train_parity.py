@@ -449,6 +449,7 @@ def test_lanes_match_single_stream(gpu, monkeypatch):
             h.call('dr_backward', B, gpu.stream)
             gpu.sync()
             grads.append(flat_grads_by_name(gpu, h, cfg))
+        h.call('dr_set_fusion', 0)                         # (with lanes the hourglass bottoms are never fused: same launches on both handles)
         maps = gpu.forward_eval(h, ndm)
         h.close()
         return grads, maps

@@ -4,7 +4,7 @@
 // BatchReNorm is a folded scale | shift per channel (ops.py:173-180), nothing couples the crops of a batch, and below 16x16 a
 // layer is a few thousand rows: every one of those launches is a 5-10 us dependent chain that cannot fill the chip, and the part of
 // the hourglass below 16x16 is 29 of them (24 convolutions, 3 pools, 2 upsample-adds) per stack.  Here ONE workgroup takes ONE crop
-// through all of it with every intermediate tensor in LDS (160 KB per CU on gfx950; 80 KB used at F = 128):
+// through all of it with every intermediate tensor in LDS (160 KB per CU on gfx950; 84 KB used at F = 128):
 //
 //     A  = pool(x @16x16)                       8x8 x F       x: the hourglass level's input in HBM
 //     A  = res0(A)                               lower1 @8
@@ -20,8 +20,8 @@
 // the column tiles w, w + 4 and ALL row tiles, so a weight fragment is fetched once per workgroup -- straight from the packed
 // weights in HBM / L2 into registers (the forward packing [Kp/16][tap][Np][16] is exactly "four consecutive k of output channel
 // n": one 16-byte load per lane and K-group, no LDS staging; all workgroups read the same weights at about the same time).
-// Activation fragments come from the LDS image [pixel][channel] (row stride C + 4 floats: an odd number of 16-byte slots, so
-// the 16 rows of a ds_read_b128 lane group fall on different banks); a 3x3 tap outside the image reads a row of zeros.
+// Activation fragments come from the LDS image [pixel][channel] (row stride C + 8 floats, see HgShape); a 3x3 tap outside the
+// image reads a row of zeros.
 // With one row tile (4x4, 2x2) the four MFMA steps of a K-group feed four independent accumulators (summed in a fixed order).
 //
 // Measured on MI355X (profiles/r04_experiments.md section 4), ICVL S=2 F=128: the launch takes 110 us at 40 crops (92 us for one
@@ -44,7 +44,7 @@ struct HgFusedParams {
 
 // floats of LDS the kernel needs for F channels
 __host__ __device__ inline int hg_fused_lds_floats(int F) {
-    const int sF = F + 4, sH = F / 2 + 4;
+    const int sF = F + 8, sH = F / 2 + 8;
     return 64 * sF + 2 * 64 * sH + 16 * sF + 4 * sF + sF;
 }
 inline bool hg_fused_supported(int F) { return F >= 32 && F % 32 == 0 && F <= 128; }
@@ -111,7 +111,11 @@ struct HgW { float4 b[9]; float sc[2], sh[2]; };
 
 template <int F> struct HgShape {
     static constexpr int H = F / 2;                // half width
-    static constexpr int sF = F + 4, sH = H + 4;   // LDS row strides (floats)
+    // LDS row strides (floats): C + 8 = 2 (mod 4) sixteen-byte slots -- a ds_read_b128 is served in four groups of 16 lanes
+    // ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) over 16 slots, and with lane (r, g) reading slot (stride r + g) mod 16 a
+    // stride of 2, 6, 10 or 14 slots keeps every group on 16 different slots; C + 4 (one slot past a multiple of 16) had one
+    // two-way conflict per group: SQ_LDS_BANK_CONFLICT was 43 % of the LDS cycles
+    static constexpr int sF = F + 8, sH = H + 8;
     static constexpr int CT1 = H / 16;             // column tiles of the half-width outputs (<= 4: one per wave)
     static constexpr int CT3 = F / 16;             // ... of the F-channel output (<= 8: up to two per wave)
     static constexpr int QC3 = CT3 > 4 ? 2 : 1;

@@ -1184,31 +1184,22 @@ static int run_fused_region(dr_handle* h, const FusedRegion& fr, int B, hipStrea
         flops += 2.0 * B * c.H * c.W * c.k * c.k * c.cin * c.cout;
     }
     const size_t lds = (size_t)hg_fused_lds_floats(p.F) * sizeof(float);
-    // waves per workgroup: 4 (one per SIMD; the default), or 8 -- the 8x8 levels' four row tiles split over two waves per SIMD
-    // (DR_HG_WAVES=8)
-    static const int nw = [] { const char* e = getenv("DR_HG_WAVES"); const int v = e ? atoi(e) : 0; return v == 8 ? 8 : 4; }();
+    // (four waves per workgroup, one per SIMD; a variant with eight -- the 8x8 levels' row tiles split over two waves per SIMD --
+    // measured equal, profiles/r04_experiments.md, and is not instantiated)
     static const bool lds_ok = [] {
         bool ok = true;
         ok = ok && rt::allow_dyn_lds((const void*)hg_tail_eval_kernel<96, 4>, (size_t)hg_fused_lds_floats(96) * sizeof(float));
         ok = ok && rt::allow_dyn_lds((const void*)hg_tail_eval_kernel<128, 4>, (size_t)hg_fused_lds_floats(128) * sizeof(float));
-        ok = ok && rt::allow_dyn_lds((const void*)hg_tail_eval_kernel<96, 8>, (size_t)hg_fused_lds_floats(96) * sizeof(float));
-        ok = ok && rt::allow_dyn_lds((const void*)hg_tail_eval_kernel<128, 8>, (size_t)hg_fused_lds_floats(128) * sizeof(float));
         return ok;
     }();
     if (!lds_ok) DR_FAIL(h, DR_E_DEVICE, "fused hourglass bottom: %zu bytes of LDS per workgroup refused", lds);
     ProfScope ps(h, s, KID_HG_FUSED, flops, 4.0 * B * p.F * (256.0 + 64.0));
-#define DR_HG_LAUNCH(FF)                                                                                          \
-    do {                                                                                                          \
-        if (nw == 8) DR_LAUNCH((hg_tail_eval_kernel<FF, 8>), dim3(B), dim3(512), lds, s, p);                      \
-        else DR_LAUNCH((hg_tail_eval_kernel<FF, 4>), dim3(B), dim3(256), lds, s, p);                              \
-    } while (0)
     switch (p.F) {                                              // (hg_fused_supported: multiples of 32 up to 128)
-        case 32: DR_HG_LAUNCH(32); break;
-        case 64: DR_HG_LAUNCH(64); break;
-        case 96: DR_HG_LAUNCH(96); break;
-        default: DR_HG_LAUNCH(128); break;
+        case 32: DR_LAUNCH((hg_tail_eval_kernel<32, 4>), dim3(B), dim3(256), lds, s, p); break;
+        case 64: DR_LAUNCH((hg_tail_eval_kernel<64, 4>), dim3(B), dim3(256), lds, s, p); break;
+        case 96: DR_LAUNCH((hg_tail_eval_kernel<96, 4>), dim3(B), dim3(256), lds, s, p); break;
+        default: DR_LAUNCH((hg_tail_eval_kernel<128, 4>), dim3(B), dim3(256), lds, s, p); break;
     }
-#undef DR_HG_LAUNCH
     return DR_OK;
 }
 

@@ -199,8 +199,9 @@ def test_pipeline_ragged_batches_and_depth_switch(gpu):
 
 
 def test_rejected_forward_leaves_the_slots_alone_and_inputs_may_be_recycled(be):
-    """Depth 2: (a) a dr_forward_train the library rejects (batch above max_batch) moves no state -- the micro-step enqueued before
-    it can still be continued with dr_loss / dr_backward and gives the gradient of an undisturbed run; (b) the caller's crops,
+    """Depth 2: (a) a dr_forward_train the library rejects (batch above max_batch) moves no state, its dropout arguments included
+    -- the micro-step enqueued before it can still be continued with dr_loss / dr_backward and gives the gradient of an undisturbed
+    run; (b) the caller's crops,
     poses, camera parameters and centres of mass are copied in the caller's stream order, so overwriting them right behind the
     calls changes nothing (include/densereg.h); (c) depth 2 -> 1 -> 2 -> close releases every stream and event exactly once."""
     from densereg_amd._lib import DenseRegError
@@ -214,10 +215,10 @@ def test_rejected_forward_leaves_the_slots_alone_and_inputs_may_be_recycled(be):
         h.call('dr_zero_grad', be.stream)
         for i in range(1 if be.name == 'emu' else 2):              # (the emulator runs every thread as a fiber: one micro-step there)
             bufs = [be.dev(np.ascontiguousarray(a)) for a in batches[i]]
-            h.call('dr_forward_train', B, be.ptr(bufs[0]), 0, None, C.c_uint64(0), be.stream)
-            if disturb:
+            h.call('dr_forward_train', B, be.ptr(bufs[0]), 2, None, C.c_uint64(5 + i), be.stream)      # dropout on (in-kernel hash)
+            if disturb:                                  # rejected, and with OTHER dropout arguments: the backward below must not see them
                 with pytest.raises(DenseRegError):
-                    h.call('dr_forward_train', B + 1, be.ptr(bufs[0]), 0, None, C.c_uint64(0), be.stream)
+                    h.call('dr_forward_train', B + 1, be.ptr(bufs[0]), 0, None, C.c_uint64(99), be.stream)
             h.call('dr_loss', B, be.ptr(bufs[0]), be.ptr(bufs[1]), be.ptr(bufs[2]), be.ptr(bufs[3]), None, be.stream)
             if disturb:                                  # recycle the inputs in stream order, right behind the calls
                 for b in bufs:

@@ -48,6 +48,7 @@ struct BnTrainParams {
     // the partial rows of group g are rows [g*rows_per_group, (g+1)*rows_per_group) of `part`; scale | shift and bnc of group g
     // live fold_stride / bnc_stride floats behind group g-1's.  groups <= 1: one batch, M rows (everything above as it was).
     int groups; int rows_per_group; long Mg; long fold_stride; long bnc_stride;
+    int fin_split;                              // finalize launch: waves per group (launch_bn_*_finalize sets it)
     float r_max_g[8], d_max_g[8];               // the schedule scalars of groups 0..groups-1 (r_max / d_max above = group 0's)
 };
 constexpr int kMaxGroups = 8;
@@ -111,13 +112,16 @@ __device__ __forceinline__ BnChanIn bn_channel_load(const BnTrainParams& p, int 
 //   bn_channel_advance  `st` -> what this batch leaves behind (moving averages, zero-debias accumulators; `step` = the batch's
 //                       update count, for the debias correction);  bn_channel_store_state writes it back
 struct BnChanOut { float scale, shift, mean, var, inv_std, r, d; };
-__device__ __forceinline__ BnChanOut bn_channel_math(const BnTrainParams& p, const BnChanIn& st, double sum, double sq, double cnt, float r_max,
-                                                     float d_max) {
-    BnChanOut o;
+__device__ __forceinline__ void bn_channel_moments(double sum, double sq, double cnt, float& mean, float& var) {
     const double mean_d = sum / cnt;
     double var_d = sq / cnt - mean_d * mean_d;
     if (var_d < 0.0) var_d = 0.0;
-    o.mean = (float)mean_d; o.var = (float)var_d;
+    mean = (float)mean_d; var = (float)var_d;
+}
+__device__ __forceinline__ BnChanOut bn_channel_math(const BnTrainParams& p, const BnChanIn& st, double sum, double sq, double cnt, float r_max,
+                                                     float d_max) {
+    BnChanOut o;
+    bn_channel_moments(sum, sq, cnt, o.mean, o.var);
     const float std_b = sqrtf(o.var + p.eps);
     o.inv_std = 1.0f / std_b;
     const float mstd = sqrtf(st.mv + p.eps);
@@ -141,18 +145,22 @@ __device__ __forceinline__ void bn_channel_store(const BnTrainParams& p, int c, 
     bnc[2 * p.C + c] = o.r;
     bnc[3 * p.C + c] = o.d;
 }
-__device__ __forceinline__ void bn_channel_advance(const BnTrainParams& p, BnChanIn& st, const BnChanOut& o, int step) {
+// (the zero-debias correction of update `step`, ops.py:156-162; split off so that the chain over micro-batch groups can have it ready)
+__device__ __forceinline__ float bn_debias_corr(const BnTrainParams& p, int step) { return 1.0f - powf(p.decay, (float)step); }
+__device__ __forceinline__ void bn_channel_advance_with(const BnTrainParams& p, BnChanIn& st, float mean, float var, float corr) {
     const float om = 1.0f - p.decay;
     if (p.shadow_step > 0) {
-        st.sh_m = st.sh_m - (st.sh_m - o.mean) * om;
-        st.sh_v = st.sh_v - (st.sh_v - o.var) * om;
-        const float corr = 1.0f - powf(p.decay, (float)step);
+        st.sh_m = st.sh_m - (st.sh_m - mean) * om;
+        st.sh_v = st.sh_v - (st.sh_v - var) * om;
         st.mm = st.sh_m / corr;
         st.mv = st.sh_v / corr;
     } else {
-        st.mm = st.mm - (st.mm - o.mean) * om;
-        st.mv = st.mv - (st.mv - o.var) * om;
+        st.mm = st.mm - (st.mm - mean) * om;
+        st.mv = st.mv - (st.mv - var) * om;
     }
+}
+__device__ __forceinline__ void bn_channel_advance(const BnTrainParams& p, BnChanIn& st, const BnChanOut& o, int step) {
+    bn_channel_advance_with(p, st, o.mean, o.var, p.shadow_step > 0 ? bn_debias_corr(p, step) : 1.0f);
 }
 __device__ __forceinline__ void bn_channel_store_state(const BnTrainParams& p, int c, const BnChanIn& st) {
     if (p.shadow_step > 0) { p.shadow_mean[c] = st.sh_m; p.shadow_var[c] = st.sh_v; }
@@ -229,31 +237,76 @@ __global__ __launch_bounds__(256) void bias_grad_from_rows_kernel(const double* 
     if ((threadIdx.x & 63) == 0) dst[c] += (float)sum;
 }
 
-__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const BnTrainParams p) {
+// The finalize launches (forward here, backward below): ONE workgroup per channel, groups x fin_split waves.  Wave (g, sub) folds
+// the sub-th share of micro-batch group g's partial rows (one coalesced round trip per 512 rows, all groups' loads in flight
+// together), the shares meet in LDS, thread 0 adds them in a fixed order and walks the groups' chain of state updates in registers.
+// (Rounds 1-3: four channels per workgroup, one wave per channel folding group after group -- a round trip per group behind
+// the previous group's arithmetic, 14-23 us per launch at five groups and up to 0.4 ms where a 128x128 layer's 12 800 rows went
+// through 32 workgroups; 134 such launches in each direction per window.)
+constexpr int kBnFinalizeWaves = 16;
+// partial rows one wave folds before its group gets a second wave (DR_BN_FIN_ROWS; test hook: dr_dbg_bn_finalize_rows)
+inline int g_bn_finalize_rows = [] { const char* e = getenv("DR_BN_FIN_ROWS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+inline int bn_finalize_split(int groups, int rows_per_group) {
+    const int g = groups > 1 ? groups : 1;
+    const int want = (rows_per_group + g_bn_finalize_rows - 1) / g_bn_finalize_rows, cap = kBnFinalizeWaves / g;
+    return want < 1 ? 1 : (want > cap ? (cap < 1 ? 1 : cap) : want);
+}
+// this wave's share of its group's rows -> s_a / s_b[wave]; returns after the barrier
+__device__ __forceinline__ void bn_finalize_fold(const double* part, int part_rows, int C, int c, int groups, int rows_per_group, int split,
+                                                 double* s_a, double* s_b) {
+    const int wave = threadIdx.x >> 6, g = wave / split, sub = wave - g * split;
+    const int chunk = (rows_per_group + split - 1) / split;
+    const int r0 = sub * chunk;
+    int n = rows_per_group - r0;
+    n = n > chunk ? chunk : (n < 0 ? 0 : n);
+    double a = 0.0, b = 0.0;
+    if (g < groups) fold_partials_wave(part, part_rows, C, c, g * rows_per_group + r0, n, a, b);
+    if ((threadIdx.x & 63) == 0) { s_a[wave] = a; s_b[wave] = b; }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64 * kBnFinalizeWaves) void bn_fwd_finalize_kernel(const BnTrainParams p) {
     DR_PIN_ARGS(p.part, p.part_rows, p.C, p.M, p.beta, p.gamma, p.mm, p.mv, p.mm_next, p.mv_next, p.shadow_mean, p.shadow_var, p.shadow_step, p.scale, p.shift, p.bnc);
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= p.C) return;
-    if (p.groups > 1) {                                   // micro-batch groups: the chain of their state updates, in order
-        BnChanIn st = bn_channel_load(p, c);
-        for (int g = 0; g < p.groups; ++g) {
-            double sum, sq;
-            fold_partials_wave(p.part, p.part_rows, p.C, c, g * p.rows_per_group, p.rows_per_group, sum, sq);
-            if ((threadIdx.x & 63) == 0) {                    // group g reads the state group g-1 left, in registers
-                const BnChanOut o = bn_channel_math(p, st, sum, sq, (double)p.Mg, p.r_max_g[g], p.d_max_g[g]);
-                bn_channel_store(p, c, o, g);
-                bn_channel_advance(p, st, o, p.shadow_step + g);
-            }
-        }
-        if ((threadIdx.x & 63) == 0) bn_channel_store_state(p, c, st);
-        return;
+    __shared__ double s_a[kBnFinalizeWaves], s_b[kBnFinalizeWaves];
+    const int c = blockIdx.x;
+    const int G = p.groups > 1 ? p.groups : 1;
+    const int rpg = p.groups > 1 ? p.rows_per_group : p.part_rows;
+    BnChanIn st{};
+    if (threadIdx.x < 64) st = bn_channel_load(p, c);         // beside the fold's round trip, not behind it (wave 0, every lane)
+    bn_finalize_fold(p.part, p.part_rows, p.C, c, G, rpg, p.fin_split, s_a, s_b);
+    if (threadIdx.x >= 64) return;
+    // wave 0.  Lane g: group g.  What does not depend on the chain -- the batch moments, the debias correction (a powf) -- in
+    // parallel; the chain itself (moving statistics after group g-1 -> before group g: two multiply-adds and two divisions per
+    // group, ops.py:156-162) in every lane; then lane g finishes its group against the state it caught on the way.  Same
+    // arithmetic per group as bn_channel_math / bn_channel_advance (one thread, group after group: 7 us of dependent
+    // arithmetic at five groups).
+    const int lane = threadIdx.x;
+    const double cnt = p.groups > 1 ? (double)p.Mg : (double)p.M;
+    double sum = 0.0, sq = 0.0;
+    float mean = 0.f, var = 0.f, corr = 1.f, r_max = p.r_max, d_max = p.d_max;
+    if (lane < G) {
+        for (int k = 0; k < p.fin_split; ++k) { sum += s_a[lane * p.fin_split + k]; sq += s_b[lane * p.fin_split + k]; }
+        bn_channel_moments(sum, sq, cnt, mean, var);
+        if (p.shadow_step > 0) corr = bn_debias_corr(p, p.shadow_step + lane);
     }
-    const BnChanIn in = bn_channel_load(p, c);
-    double sum, sq;
-    fold_partials_wave(p.part, p.part_rows, p.C, c, sum, sq);
-    if ((threadIdx.x & 63) == 0) {
-        float sc, sh;
-        bn_channel_coeffs(p, c, in, sum, sq, sc, sh, true);
+    if (p.groups > 1) {
+#pragma unroll
+        for (int g = 0; g < kMaxGroups; ++g)
+            if (lane == g) { r_max = p.r_max_g[g]; d_max = p.d_max_g[g]; }
     }
+    BnChanIn cur = st, mine = st;
+    for (int g = 0; g < G; ++g) {
+        const float m_g = __shfl(mean, g), v_g = __shfl(var, g), c_g = __shfl(corr, g);
+        if (lane == g) mine = cur;                            // the state group g reads: what group g-1 left
+        bn_channel_advance_with(p, cur, m_g, v_g, c_g);
+    }
+    if (lane < G) bn_channel_store(p, c, bn_channel_math(p, mine, sum, sq, cnt, r_max, d_max), lane);
+    if (lane == 0) bn_channel_store_state(p, c, cur);
+}
+inline void launch_bn_fwd_finalize(BnTrainParams& p, hipStream_t s) {
+    const int G = p.groups > 1 ? p.groups : 1;
+    p.fin_split = bn_finalize_split(G, p.groups > 1 ? p.rows_per_group : p.part_rows);
+    DR_LAUNCH(bn_fwd_finalize_kernel, dim3(p.C), dim3(64 * G * p.fin_split), 0, s, p);
 }
 
 // FUSE: layers with few partial rows (everything at 8x8 and below) skip the finalize launch -- every workgroup
@@ -405,6 +458,7 @@ struct BnBwdParams {
     // micro-batch groups (BnTrainParams): per-group sums, coefficients (coef of group g: 3*C floats behind group g-1's) and
     // forward values (scale | shift, bnc copies fold_stride / bnc_stride floats apart); dbeta / dgamma sum over the groups
     int groups; int rows_per_group; long Mg; long fold_stride; long bnc_stride;
+    int fin_split;                              // finalize launch: waves per group (launch_bn_*_finalize sets it)
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p_in) {
@@ -491,42 +545,44 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p_
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdParams p) {
+// (mapping: bn_fwd_finalize_kernel)  coefficients per group; dbeta / dgamma summed over the groups in order
+__global__ __launch_bounds__(64 * kBnFinalizeWaves) void bn_bwd_finalize_kernel(const BnBwdParams p) {
     DR_PIN_ARGS(p.part, p.part_rows, p.C, p.M, p.gamma, p.bnc, p.coef, p.dbeta, p.dgamma);
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= p.C) return;
-    if (p.groups > 1) {                                   // micro-batch groups: coefficients per group, dbeta / dgamma summed in order
-        const float gam = p.gamma[c];
-        float db = p.dbeta[c], dg = p.dgamma[c];
-        for (int g = 0; g < p.groups; ++g) {
-            const float* bnc = p.bnc + (long)g * p.bnc_stride;
-            const float r = bnc[2 * p.C + c], d = bnc[3 * p.C + c], istd = bnc[p.C + c];
-            double sg, sgy;
-            fold_partials_wave(p.part, p.part_rows, p.C, c, g * p.rows_per_group, p.rows_per_group, sg, sgy);
-            if ((threadIdx.x & 63) == 0) {
-                float* coef = p.coef + (long)g * 3 * p.C;
-                coef[0 * p.C + c] = gam * r * istd;
-                coef[1 * p.C + c] = (float)(sg / (double)p.Mg);
-                coef[2 * p.C + c] = (float)(sgy / (double)p.Mg);
-                db = db + (float)sg;
-                dg = dg + (r * (float)sgy + d * (float)sg);
-            }
-        }
-        if ((threadIdx.x & 63) == 0) { p.dbeta[c] = db; p.dgamma[c] = dg; }
-        return;
+    __shared__ double s_a[kBnFinalizeWaves], s_b[kBnFinalizeWaves];
+    const int c = blockIdx.x;
+    const int G = p.groups > 1 ? p.groups : 1;
+    const int rpg = p.groups > 1 ? p.rows_per_group : p.part_rows;
+    const double Mg = p.groups > 1 ? (double)p.Mg : (double)p.M;
+    // wave 0, lane g: group g.  Everything the last lines read, before the fold (one round trip beside the fold's, not behind it)
+    float r = 0.f, d = 0.f, istd = 0.f, gam = 0.f, db = 0.f, dg = 0.f;
+    if (threadIdx.x < 64) {
+        const float* bnc = p.bnc + (long)((int)threadIdx.x < G ? (int)threadIdx.x : 0) * p.bnc_stride;
+        r = bnc[2 * p.C + c]; d = bnc[3 * p.C + c]; istd = bnc[p.C + c];
+        gam = p.gamma[c]; db = p.dbeta[c]; dg = p.dgamma[c];
     }
-    // everything the last lines read, before the fold (one round trip beside the fold's instead of one behind it)
-    const float r = p.bnc[2 * p.C + c], d = p.bnc[3 * p.C + c], istd = p.bnc[p.C + c], gam = p.gamma[c];
-    const float db0 = p.dbeta[c], dg0 = p.dgamma[c];
-    double sg, sgy;
-    fold_partials_wave(p.part, p.part_rows, p.C, c, sg, sgy);
-    if ((threadIdx.x & 63) == 0) {
-        p.coef[0 * p.C + c] = gam * r * istd;
-        p.coef[1 * p.C + c] = (float)(sg / (double)p.M);
-        p.coef[2 * p.C + c] = (float)(sgy / (double)p.M);
-        p.dbeta[c] = db0 + (float)sg;
-        p.dgamma[c] = dg0 + (r * (float)sgy + d * (float)sg);
+    bn_finalize_fold(p.part, p.part_rows, p.C, c, G, rpg, p.fin_split, s_a, s_b);
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    double sg = 0.0, sgy = 0.0;
+    if (lane < G) {
+        for (int k = 0; k < p.fin_split; ++k) { sg += s_a[lane * p.fin_split + k]; sgy += s_b[lane * p.fin_split + k]; }
+        float* coef = p.coef + (long)lane * 3 * p.C;
+        coef[0 * p.C + c] = gam * r * istd;
+        coef[1 * p.C + c] = (float)(sg / Mg);
+        coef[2 * p.C + c] = (float)(sgy / Mg);
     }
+    const float fsg = (float)sg, fsgy = (float)sgy;
+    for (int g = 0; g < G; ++g) {                             // dbeta / dgamma: the groups' terms added in order
+        const float a = __shfl(fsg, g), b = __shfl(fsgy, g), rg = __shfl(r, g), dgp = __shfl(d, g);
+        db = db + a;
+        dg = dg + (rg * b + dgp * a);
+    }
+    if (lane == 0) { p.dbeta[c] = db; p.dgamma[c] = dg; }
+}
+inline void launch_bn_bwd_finalize(BnBwdParams& p, hipStream_t s) {
+    const int G = p.groups > 1 ? p.groups : 1;
+    p.fin_split = bn_finalize_split(G, p.groups > 1 ? p.rows_per_group : p.part_rows);
+    DR_LAUNCH(bn_bwd_finalize_kernel, dim3(p.C), dim3(64 * G * p.fin_split), 0, s, p);
 }
 
 // MODE 0: coefficients from a bn_bwd_finalize_kernel launch; 1 (FUSE): fold the few partial rows here; 2: look-back hand-off

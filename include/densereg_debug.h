@@ -95,6 +95,11 @@ int dr_dbg_force_bf16(int on);
  * writes draw as bf16 elements (the executor stores a BatchReNorm layer's dRaw that way on the bf16 path). */
 int dr_dbg_force_bf16_storage(int on);
 
+/* Partial statistics rows one wave of a BatchReNorm finalize launch folds before the micro-batch group gets another wave
+ * (densereg_amd/csrc/train_kernels.h: bn_finalize_split; default 512, 0 restores it).  Process-global; tests lower it so that
+ * small layers run the several-waves-per-group path. */
+int dr_dbg_bn_finalize_rows(int rows);
+
 /* Force the conv tile of every following launch (-1 = heuristic; ids as in dr_dbg_conv_bench).
  * Process-global; tests use it to check every tile shape against the reference. */
 int dr_dbg_force_tile(int tile);

@@ -159,6 +159,23 @@ def test_bn_layer_forward_backward_own_reduce(be):
         assert paths >= {(True, True), (False, False)}, paths          # fused fold and finalize launch both ran
 
 
+def test_bn_layer_finalize_launch_with_several_waves_per_channel(be):
+    """The finalize launches (one workgroup per channel; a wave per 512 partial rows, train_kernels.h: bn_finalize_split) with
+    the threshold lowered to 16 rows: the 50 statistics rows of a 2x56x57 layer fold through four waves, forward and backward
+    (the backward sums from a consumer's dgrad; the layer's own reduce pass writes few rows: the fused fold).  At the default
+    threshold the 40x32x32x256 layer of CASES_GPU (640 rows: two waves) runs that path in the tests around this one -- a seed
+    there is a seed without a ReLU knife edge: 2 of that layer's 10 485 760 pre-activations within 4e-8 of zero flip the mask
+    against fp64 with seed 5, and one flipped element is 1.7e-2 of draw's max."""
+    assert be.dbg.dr_dbg_bn_finalize_rows(16) == 0
+    try:
+        fr, br, clipped = _run(be, 2, 56, 57, 8, 12, 1, relu=True, with_res=True, seed=3)
+        assert fr > 48, fr                                     # (48 rows and fewer: no finalize launch at all)
+        fr, br, _ = _run(be, 2, 56, 57, 8, 12, 1, relu=True, consumer=(1, 9), seed=4)
+        assert fr > 48 and br > 48, (fr, br)
+    finally:
+        be.dbg.dr_dbg_bn_finalize_rows(0)
+
+
 def test_bn_layer_backward_sums_from_the_consumers_dgrad(be):
     """A consumer conv given: its dgrad launch writes dOut AND the layer's sum(g), sum(g*yhat) partial rows in the epilogue
     (plan_backward's single-reader path) -- against the same fp64 autograd, not against the unfused path."""

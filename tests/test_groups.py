@@ -221,10 +221,19 @@ def test_groups_window_against_the_oracles_chained_micro_steps(be):
     h.call('dr_set_groups', G)
     d = [be.dev(a) for a in (ndm, poses, cfgs, coms)]
     d_mask, d_lo = be.dev(np.ascontiguousarray(np.stack(masks))), be.empty((G, 4))
-    h.call('dr_forward_train', B, be.ptr(d[0]), 1, be.ptr(d_mask), C.c_uint64(0), be.stream)
-    h.call('dr_loss', B, be.ptr(d[0]), be.ptr(d[1]), be.ptr(d[2]), be.ptr(d[3]), be.ptr(d_lo), be.stream)
-    h.call('dr_backward', B, be.stream)
-    be.sync()
+    if be.name == 'emu':
+        # the BatchReNorm finalize launches give a micro-batch group several waves from 512 statistics rows on (train_kernels.h:
+        # bn_finalize_split; the full-size window tests of tests/test_bench_shapes.py run there): from 16 rows on here, so the
+        # larger layers of this small case take that path too (the emulator library carries the hook; process-global)
+        assert be.dbg.dr_dbg_bn_finalize_rows(16) == 0
+    try:
+        h.call('dr_forward_train', B, be.ptr(d[0]), 1, be.ptr(d_mask), C.c_uint64(0), be.stream)
+        h.call('dr_loss', B, be.ptr(d[0]), be.ptr(d[1]), be.ptr(d[2]), be.ptr(d[3]), be.ptr(d_lo), be.stream)
+        h.call('dr_backward', B, be.stream)
+        be.sync()
+    finally:
+        if be.name == 'emu':
+            be.dbg.dr_dbg_bn_finalize_rows(0)
     np.testing.assert_allclose(be.host(d_lo).reshape(G, 4), np.array(want_lo), rtol=3e-4)
     got = h.read_params()
     for k in p:

@@ -252,6 +252,7 @@ struct dr_handle {
     bool bn_lookback = false;
     bool bf16_act = true;                                   // DR_BF16_ACT=0: single-conv-reader activations stay fp32 on the bf16 path
     bool bf16_draw = true;                                  // DR_BF16_DRAW=0: dRaw stays fp32 on the bf16 matrix-core path (train_exec.inc)
+    bool bf16_raw = true;                                   // DR_BF16_RAW=0: the raw outputs of BatchReNorm convs stay fp32 on that path (train_exec.inc)
     bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold
     const float* dm_train = nullptr;                       // input of the last dr_forward_train
     // micro-step slots (StepSlot above)

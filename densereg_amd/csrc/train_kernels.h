@@ -40,6 +40,7 @@ struct BnTrainParams {
     int relu;
     View res, out;
     int* flag; int flag_target;                 // look-back hand-off (bn_train_apply_kernel<2>): groups published so far / wanted
+    int raw_bf16;                               // raw holds bf16 elements (same element stride raw_cs): the conv epilogue stored it that way (ConvParams::y_bf16)
     int out_bf16;                               // out holds bf16 elements (same element stride out.cs; whole channel groups of four,
                                                 // no residual): the activation's only readers round it to bf16 while staging
     // Micro-batch groups (dr_set_groups): the M rows are `groups` consecutive micro-batches of Mg rows each -- the reference's
@@ -95,6 +96,24 @@ __device__ __forceinline__ void bn_handoff_wait(int* flag, int target) {
 #define DR_BN_ROWS 4                     // experiment switch of the build (profiles/r02_experiments.md)
 #endif
 constexpr int kBnRows = DR_BN_ROWS;
+
+// four consecutive channels of the raw conv output at element offset `e` (a multiple of 4): fp32 storage, or (R16) bf16 storage on
+// the bf16 path -- half the bytes of the tensor every BatchReNorm pass reads.  A COMPILE-TIME variant of the streaming kernels:
+// as a run-time branch around the loads it kept hipcc from issuing a thread's loads as one batch (measured: the backward reduce
+// pass 4.8 -> 7.9 ms per three windows with HALF the raw bytes; profiles/r04_experiments.md section 9).
+template <int R16>
+__device__ __forceinline__ float4 bn_load_raw4(const float* raw, long e) {
+    if (R16) {
+        const dr_bf16x4 h = *reinterpret_cast<const dr_bf16x4*>(reinterpret_cast<const __bf16*>(raw) + e);
+        const dr_f32x4 f = __builtin_convertvector(h, dr_f32x4);
+        return make_float4(f[0], f[1], f[2], f[3]);
+    }
+    return *reinterpret_cast<const float4*>(raw + e);
+}
+template <int R16>
+__device__ __forceinline__ const float* bn_raw_advance(const float* raw, long elems) {
+    return R16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(raw) + elems) : raw + elems;
+}
 
 // The per-channel inputs of bn_channel_coeffs, loaded BEFORE the partial rows are folded (unconditional: the shadow slots exist
 // for every BatchReNorm layer): the finalize launches are 5 us chains of dependent round trips, this one now overlaps the fold's.
@@ -313,13 +332,13 @@ inline void launch_bn_fwd_finalize(BnTrainParams& p, hipStream_t s) {
 // folds the rows itself (serially per channel, fixed order, a few L2 hits) and workgroup 0 persists the results.
 // MODE 0: coefficients come from a bn_fwd_finalize_kernel launch; 1 (FUSE): few partial rows, every workgroup folds them;
 // 2: look-back hand-off (above).
-template <int MODE>
+template <int MODE, int R16 = 0>
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams p_in) {
     DR_PIN_ARGS(p_in.raw, p_in.raw_cs, p_in.M, p_in.C, p_in.scale, p_in.shift, p_in.relu, p_in.res.p, p_in.res.cs, p_in.res.coff, p_in.out.p, p_in.out.cs, p_in.out.coff, p_in.out_bf16, p_in.part, p_in.part_rows, (int)gridDim.x);
     BnTrainParams p = p_in;
     if (MODE == 0 && p.groups > 1) {                      // blockIdx.y = micro-batch group: its rows, its coefficients
         const long g = blockIdx.y, r0 = g * p.Mg;
-        p.raw += r0 * p.raw_cs;
+        p.raw = bn_raw_advance<R16>(p.raw, r0 * p.raw_cs);
         if (p.res.p) p.res.p += r0 * p.res.cs;
         if (p.out_bf16) p.out.p = reinterpret_cast<float*>(reinterpret_cast<__bf16*>(p.out.p) + r0 * p.out.cs);
         else p.out.p += r0 * p.out.cs;
@@ -393,7 +412,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
 #pragma unroll
         for (int u = 0; u < kBnRows; ++u) {
             const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;     // tail rows re-read the last row
-            x[u] = *reinterpret_cast<const float4*>(p.raw + mc * p.raw_cs + cg * 4);
+            x[u] = bn_load_raw4<R16>(p.raw, mc * p.raw_cs + cg * 4);
         }
         if (vec_res) {
 #pragma unroll
@@ -452,6 +471,7 @@ struct BnBwdParams {
     float* draw;                      // out: gradient wrt the raw conv output, dense stride raw_cs
     View dres; int dres_acc;          // apply pass, nullable: residual source's gradient (+)= dOut (out = act(..) + res)
     int* flag; int flag_target;       // look-back hand-off (bn_bwd_apply_kernel<2>)
+    int raw_bf16;                     // raw holds bf16 elements (BnTrainParams::raw_bf16)
     int draw_bf16;                    // draw holds bf16 elements (same element stride raw_cs): both of its readers -- the layer's
                                       // dgrad and weight gradient on the bf16 matrix cores -- round it to bf16 anyway
                                       // while staging, so the numbers are the same and the tensor is half the bytes
@@ -461,13 +481,15 @@ struct BnBwdParams {
     int fin_split;                              // finalize launch: waves per group (launch_bn_*_finalize sets it)
 };
 
+template <int R16 = 0>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p_in) {
     DR_PIN_ARGS(p_in.dout.p, p_in.dout.cs, p_in.dout.coff, p_in.raw, p_in.raw_cs, p_in.M, p_in.C, p_in.relu, p_in.scale, p_in.shift, p_in.bnc, p_in.part, (int)gridDim.x);
     BnBwdParams p = p_in;
     int part_row = (int)blockIdx.x, part_rows = (int)gridDim.x;
     if (p.groups > 1) {                                   // blockIdx.y = micro-batch group
         const long g = blockIdx.y, r0 = g * p.Mg;
-        p.dout.p += r0 * p.dout.cs; p.raw += r0 * p.raw_cs;
+        p.dout.p += r0 * p.dout.cs;
+        p.raw = bn_raw_advance<R16>(p.raw, r0 * p.raw_cs);
         p.scale += g * p.fold_stride; p.shift += g * p.fold_stride; p.bnc += g * p.bnc_stride;
         p.M = p.Mg;
         part_row += (int)g * (int)gridDim.x; part_rows *= (int)gridDim.y;
@@ -495,7 +517,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p_
 #pragma unroll
             for (int u = 0; u < kBnRows; ++u) {
                 const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
-                x4[u] = *reinterpret_cast<const float4*>(p.raw + mc * p.raw_cs + cg * 4);
+                x4[u] = bn_load_raw4<R16>(p.raw, mc * p.raw_cs + cg * 4);
             }
             if (vec_d) {
 #pragma unroll
@@ -586,13 +608,14 @@ inline void launch_bn_bwd_finalize(BnBwdParams& p, hipStream_t s) {
 }
 
 // MODE 0: coefficients from a bn_bwd_finalize_kernel launch; 1 (FUSE): fold the few partial rows here; 2: look-back hand-off
-template <int MODE>
+template <int MODE, int R16 = 0>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_in) {
     DR_PIN_ARGS(p_in.dout.p, p_in.dout.cs, p_in.dout.coff, p_in.raw, p_in.raw_cs, p_in.M, p_in.C, p_in.relu, p_in.scale, p_in.shift, p_in.bnc, p_in.coef, p_in.draw, p_in.dres.p, p_in.dres.cs, p_in.dres.coff, p_in.dres_acc, p_in.draw_bf16, p_in.part, p_in.part_rows);
     BnBwdParams p = p_in;
     if (MODE == 0 && p.groups > 1) {                      // blockIdx.y = micro-batch group: its rows, its coefficients
         const long g = blockIdx.y, r0 = g * p.Mg;
-        p.dout.p += r0 * p.dout.cs; p.raw += r0 * p.raw_cs;
+        p.dout.p += r0 * p.dout.cs;
+        p.raw = bn_raw_advance<R16>(p.raw, r0 * p.raw_cs);
         if (p.draw_bf16) p.draw = reinterpret_cast<float*>(reinterpret_cast<__bf16*>(p.draw) + r0 * p.raw_cs);
         else p.draw += r0 * p.raw_cs;
         if (p.dres.p) p.dres.p += r0 * p.dres.cs;
@@ -666,7 +689,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_i
 #pragma unroll
         for (int u = 0; u < kBnRows; ++u) {
             const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
-            x4[u] = *reinterpret_cast<const float4*>(p.raw + mc * p.raw_cs + cg * 4);
+            x4[u] = bn_load_raw4<R16>(p.raw, mc * p.raw_cs + cg * 4);
         }
         if (vec_d) {
 #pragma unroll

@@ -75,6 +75,7 @@ struct ConvParams {
     // BF kernels only (the epilogue's EP_IO16): the raw output of a BatchReNorm conv stored as bf16 elements (y_cs / y_coff in
     // elements; plain output only: no scale / shift / relu / res / dropout / bst) -- the statistics rows are sums over the ROUNDED
     // values, so the layer normalises exactly what it stored; and the producer's raw output read back that way by bst mode.
+    // y_bf16 together with bst_raw_bf16: the input gradient this launch is the only writer of (no res), stored as bf16 elements.
     int y_bf16, bst_raw_bf16;
 };
 
@@ -545,11 +546,11 @@ __global__ __launch_bounds__(256, (MF == 16 ? 5 : WK > 1 ? (BN > 96 ? 3 : 4) : c
     constexpr int EP_BATCH_ROWS = MF == 16 ? 4 : (BM * BN >= 128 * 128 || BK_ == 64) ? 16 : 8;
     constexpr int EP_TS = MF, EP_NR = NR;
     const int ep_lg = MF == 16 ? (lane >> 4) : lk, ep_lc = MF == 16 ? (lane & 15) : li;
-    if (BF != 0 && p.y_bf16) {                               // bf16 kernels: one copy of the epilogue per storage case (conv_epilogue.inc)
-        constexpr bool EP_Y16 = true, EP_B16 = false, EP_B16_CONST = false;
-#include "conv_epilogue.inc"
-    } else if (BF != 0 && p.bst_raw_bf16) {
+    if (BF != 0 && p.bst_raw_bf16) {                         // bf16 kernels: one copy of the epilogue per storage case (conv_epilogue.inc)
         constexpr bool EP_Y16 = false, EP_B16 = true, EP_B16_CONST = true;
+#include "conv_epilogue.inc"
+    } else if (BF != 0 && p.y_bf16) {
+        constexpr bool EP_Y16 = true, EP_B16 = false, EP_B16_CONST = false;
 #include "conv_epilogue.inc"
     } else {
         constexpr bool EP_Y16 = false, EP_B16 = false, EP_B16_CONST = false;

@@ -189,11 +189,11 @@ __global__ __launch_bounds__(256, 2) void conv_splitk_kernel(const ConvParams p)
     constexpr int EP_BATCH_ROWS = 16;     // two waves per SIMD by launch bounds: room for the whole column in one batch
     constexpr int EP_TS = 32, EP_NR = 16;
     const int ep_lg = lk, ep_lc = li;
-    if (BF != 0 && p.y_bf16) {                               // bf16 kernels: one copy of the epilogue per storage case (conv_epilogue.inc)
-        constexpr bool EP_Y16 = true, EP_B16 = false, EP_B16_CONST = false;
-#include "conv_epilogue.inc"
-    } else if (BF != 0 && p.bst_raw_bf16) {
+    if (BF != 0 && p.bst_raw_bf16) {                         // bf16 kernels: one copy of the epilogue per storage case (conv_epilogue.inc)
         constexpr bool EP_Y16 = false, EP_B16 = true, EP_B16_CONST = true;
+#include "conv_epilogue.inc"
+    } else if (BF != 0 && p.y_bf16) {
+        constexpr bool EP_Y16 = true, EP_B16 = false, EP_B16_CONST = false;
 #include "conv_epilogue.inc"
     } else {
         constexpr bool EP_Y16 = false, EP_B16 = false, EP_B16_CONST = false;

@@ -162,7 +162,8 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     if (M * widest >= (1ll << 32)) return -1;
     // bf16-stored raw output / producer raw (conv_epilogue.inc, EP_IO16): the bf16 kernels only, and a plain output only
     if ((p.y_bf16 || p.bst_raw_bf16) && !p.bf16) return -1;
-    if (p.y_bf16 && (p.scale || p.shift || p.relu || p.res || p.drop || p.drop_rng || p.bst_raw || p.out_rowmask)) return -1;
+    if (p.y_bf16 && !p.bst_raw_bf16 && (p.scale || p.shift || p.relu || p.res || p.drop || p.drop_rng || p.bst_raw || p.out_rowmask)) return -1;
+    if (p.y_bf16 && p.bst_raw_bf16 && p.res) return -1;                  // a bf16-stored dOut has ONE writer
     if (p.bst_raw_bf16 && (!p.bst_raw || p.bst_act || p.scale || p.shift || p.relu || p.drop || p.drop_rng)) return -1;
     if (conv_tile_id(p) == KID_CONV_SPLITK) {
         if (p.bf16 && p.Kp % 32) return -1;
@@ -713,6 +714,8 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         h->bf16_act = !(a16 && a16[0] == '0');
         const char* b16 = getenv("DR_BF16_DRAW");
         h->bf16_draw = !(b16 && b16[0] == '0');
+        const char* ga16 = getenv("DR_BF16_GACT");
+        h->bf16_gact = !(ga16 && ga16[0] == '0');
         const char* r16 = getenv("DR_BF16_RAW");
         h->bf16_raw = !(r16 && r16[0] == '0');
         // opt-in: measured slower on MI355X (train_kernels.h, bn_handoff_wait) -- BatchReNorm 5.5 -> 8.1 ms per step

@@ -31,6 +31,8 @@ struct Tensor {
     // holds after the forward in progress.
     int reader_op = -1;
     bool is_bf16 = false;
+    bool g_bf16 = false;                // the GRADIENT buffer holds bf16 elements this backward sweep (bf16 path: written by the only
+                                        // reader's input-gradient launch, read by the producer's BatchReNorm backward apply; train_exec.inc)
 };
 
 struct TView {
@@ -252,6 +254,7 @@ struct dr_handle {
     bool bn_lookback = false;
     bool bf16_act = true;                                   // DR_BF16_ACT=0: single-conv-reader activations stay fp32 on the bf16 path
     bool bf16_draw = true;                                  // DR_BF16_DRAW=0: dRaw stays fp32 on the bf16 matrix-core path (train_exec.inc)
+    bool bf16_gact = true;                                  // DR_BF16_GACT=0: the gradient of a single-conv-reader activation stays fp32 on that path
     bool bf16_raw = true;                                   // DR_BF16_RAW=0: the raw outputs of BatchReNorm convs stay fp32 on that path (train_exec.inc)
     bool fold_is_eval = false;                             // `fold` holds the eval-mode BN fold
     const float* dm_train = nullptr;                       // input of the last dr_forward_train

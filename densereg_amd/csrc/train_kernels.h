@@ -472,6 +472,7 @@ struct BnBwdParams {
     View dres; int dres_acc;          // apply pass, nullable: residual source's gradient (+)= dOut (out = act(..) + res)
     int* flag; int flag_target;       // look-back hand-off (bn_bwd_apply_kernel<2>)
     int raw_bf16;                     // raw holds bf16 elements (BnTrainParams::raw_bf16)
+    int dout_bf16;                    // dout holds bf16 elements (stride dout.cs elements; bn_bwd_apply_kernel's D16 variant)
     int draw_bf16;                    // draw holds bf16 elements (same element stride raw_cs): both of its readers -- the layer's
                                       // dgrad and weight gradient on the bf16 matrix cores -- round it to bf16 anyway
                                       // while staging, so the numbers are the same and the tensor is half the bytes
@@ -608,13 +609,15 @@ inline void launch_bn_bwd_finalize(BnBwdParams& p, hipStream_t s) {
 }
 
 // MODE 0: coefficients from a bn_bwd_finalize_kernel launch; 1 (FUSE): fold the few partial rows here; 2: look-back hand-off
-template <int MODE, int R16 = 0>
+// D16 (with R16, the bf16 path): dOut holds bf16 elements too (BnBwdParams::dout_bf16) -- written that way by the epilogue of the
+// tensor's only reader's input-gradient launch; whole channel groups of four (the executor stores a gradient as bf16 only then)
+template <int MODE, int R16 = 0, int D16 = 0>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_in) {
     DR_PIN_ARGS(p_in.dout.p, p_in.dout.cs, p_in.dout.coff, p_in.raw, p_in.raw_cs, p_in.M, p_in.C, p_in.relu, p_in.scale, p_in.shift, p_in.bnc, p_in.coef, p_in.draw, p_in.dres.p, p_in.dres.cs, p_in.dres.coff, p_in.dres_acc, p_in.draw_bf16, p_in.part, p_in.part_rows);
     BnBwdParams p = p_in;
     if (MODE == 0 && p.groups > 1) {                      // blockIdx.y = micro-batch group: its rows, its coefficients
         const long g = blockIdx.y, r0 = g * p.Mg;
-        p.dout.p += r0 * p.dout.cs;
+        p.dout.p = D16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(p.dout.p) + r0 * p.dout.cs) : p.dout.p + r0 * p.dout.cs;
         p.raw = bn_raw_advance<R16>(p.raw, r0 * p.raw_cs);
         if (p.draw_bf16) p.draw = reinterpret_cast<float*>(reinterpret_cast<__bf16*>(p.draw) + r0 * p.raw_cs);
         else p.draw += r0 * p.raw_cs;
@@ -691,7 +694,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_i
             const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
             x4[u] = bn_load_raw4<R16>(p.raw, mc * p.raw_cs + cg * 4);
         }
-        if (vec_d) {
+        if (D16) {
+#pragma unroll
+            for (int u = 0; u < kBnRows; ++u) {
+                const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
+                const dr_bf16x4 hd = *reinterpret_cast<const dr_bf16x4*>(reinterpret_cast<const __bf16*>(p.dout.p) + mc * p.dout.cs + p.dout.coff + cg * 4);
+                const dr_f32x4 fd = __builtin_convertvector(hd, dr_f32x4);
+                d4[u] = make_float4(fd[0], fd[1], fd[2], fd[3]);
+            }
+        } else if (vec_d) {
 #pragma unroll
             for (int u = 0; u < kBnRows; ++u) {
                 const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
@@ -712,7 +723,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_i
             if (m >= p.M) break;
             const float x[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};
             float g[4] = {0.f, 0.f, 0.f, 0.f};
-            if (vec_d) {
+            if (D16 || vec_d) {
                 g[0] = d4[u].x; g[1] = d4[u].y; g[2] = d4[u].z; g[3] = d4[u].w;
             } else {
                 const float* dp = p.dout.p + m * p.dout.cs + p.dout.coff + cg * 4;

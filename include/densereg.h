@@ -201,10 +201,10 @@ int dr_depth_from_samples(const uint8_t* samples_dev, long npix, int mode, float
  * (nearest even) as they enter the matrix cores, fp32 accumulation, fp32 tensors, epilogues, heads' outputs and vote.
  * On a training handle the train-mode forward, the input-gradient and the weight-gradient convolutions follow
  * (v_mfma_f32_32x32x16_bf16 in all three); BatchReNorm arithmetic, loss, gradients, Adam and the master weights stay fp32.
- * Three kinds of INTERNAL tensors of the training step are stored as bf16 there, each read back only by kernels that would round
- * it to bf16 anyway or normalise exactly the stored values: an activation whose only reader is a convolution, the gradient with
- * respect to a BatchReNorm layer's raw output, and that raw output itself (the layer's statistics are sums over the stored
- * values).  Inputs, outputs, parameters and parameter gradients of this ABI are fp32 in both precisions.
+ * Four kinds of INTERNAL tensors of the training step are stored as bf16 there, each read back only by kernels that would round
+ * it to bf16 anyway or normalise exactly the stored values: an activation whose only reader is a convolution and its gradient,
+ * the gradient with respect to a BatchReNorm layer's raw output, and that raw output itself (the layer's statistics are sums
+ * over the stored values).  Inputs, outputs, parameters and parameter gradients of this ABI are fp32 in both precisions.
  * Call before dr_finalize_params: changing the precision un-finalizes the handle because the packed weights change type. */
 #define DR_PREC_F32 0
 #define DR_PREC_BF16 1

@@ -96,6 +96,12 @@ __device__ __forceinline__ void bn_handoff_wait(int* flag, int target) {
 #define DR_BN_ROWS 4                     // experiment switch of the build (profiles/r02_experiments.md)
 #endif
 constexpr int kBnRows = DR_BN_ROWS;
+// ... and twice as many where the raw output is stored as bf16 (the R16 variants): its loads are 8 bytes, the same bytes in flight
+// (measured, visit 15: S=2 F=128 bf16 5554 -> 5633 crops/s, config 5 508 -> 518; 8 rows on the fp32 kernels: 2654 -> 2616)
+#ifndef DR_BN_ROWS_R16
+#define DR_BN_ROWS_R16 8
+#endif
+template <int R16> struct BnRows { static constexpr int value = R16 ? DR_BN_ROWS_R16 : kBnRows; };
 
 // four consecutive channels of the raw conv output at element offset `e` (a multiple of 4): fp32 storage, or (R16) bf16 storage on
 // the bf16 path -- half the bytes of the tensor every BatchReNorm pass reads.  A COMPILE-TIME variant of the streaming kernels:
@@ -334,6 +340,7 @@ inline void launch_bn_fwd_finalize(BnTrainParams& p, hipStream_t s) {
 // 2: look-back hand-off (above).
 template <int MODE, int R16 = 0>
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams p_in) {
+    constexpr int kRows = BnRows<R16>::value;                 // rows (independent loads per tensor) a thread keeps in flight
     DR_PIN_ARGS(p_in.raw, p_in.raw_cs, p_in.M, p_in.C, p_in.scale, p_in.shift, p_in.relu, p_in.res.p, p_in.res.cs, p_in.res.coff, p_in.out.p, p_in.out.cs, p_in.out.coff, p_in.out_bf16, p_in.part, p_in.part_rows, (int)gridDim.x);
     BnTrainParams p = p_in;
     if (MODE == 0 && p.groups > 1) {                      // blockIdx.y = micro-batch group: its rows, its coefficients
@@ -407,22 +414,22 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
     const bool vec_out = full && (p.out.coff % 4 == 0) && (p.out.cs % 4 == 0);
     const bool vec_res = p.res.p && full && (p.res.coff % 4 == 0) && (p.res.cs % 4 == 0);
     const long stride = (long)nblk * rpb;
-    for (long m0 = (long)bid * rpb + rp; m0 < p.M; m0 += stride * kBnRows) {
-        float4 x[kBnRows], rv[kBnRows];
+    for (long m0 = (long)bid * rpb + rp; m0 < p.M; m0 += stride * kRows) {
+        float4 x[kRows], rv[kRows];
 #pragma unroll
-        for (int u = 0; u < kBnRows; ++u) {
+        for (int u = 0; u < kRows; ++u) {
             const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;     // tail rows re-read the last row
             x[u] = bn_load_raw4<R16>(p.raw, mc * p.raw_cs + cg * 4);
         }
         if (vec_res) {
 #pragma unroll
-            for (int u = 0; u < kBnRows; ++u) {
+            for (int u = 0; u < kRows; ++u) {
                 const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
                 rv[u] = *reinterpret_cast<const float4*>(p.res.p + mc * p.res.cs + p.res.coff + cg * 4);
             }
         }
 #pragma unroll
-        for (int u = 0; u < kBnRows; ++u) {
+        for (int u = 0; u < kRows; ++u) {
             const long m = m0 + u * stride;
             if (m >= p.M) break;
             float v[4] = {x[u].x * sc[0] + sh[0], x[u].y * sc[1] + sh[1], x[u].z * sc[2] + sh[2], x[u].w * sc[3] + sh[3]};
@@ -484,6 +491,7 @@ struct BnBwdParams {
 
 template <int R16 = 0>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p_in) {
+    constexpr int kRows = BnRows<R16>::value;                 // rows (independent loads per tensor) a thread keeps in flight
     DR_PIN_ARGS(p_in.dout.p, p_in.dout.cs, p_in.dout.coff, p_in.raw, p_in.raw_cs, p_in.M, p_in.C, p_in.relu, p_in.scale, p_in.shift, p_in.bnc, p_in.part, (int)gridDim.x);
     BnBwdParams p = p_in;
     int part_row = (int)blockIdx.x, part_rows = (int)gridDim.x;
@@ -513,22 +521,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p_
         const bool full = cg * 4 + 4 <= p.C;
         const bool vec_d = full && (p.dout.coff % 4 == 0) && (p.dout.cs % 4 == 0);
         const long stride = (long)gridDim.x * rpb;
-        for (long m0 = (long)blockIdx.x * rpb + rp; m0 < p.M; m0 += stride * kBnRows) {
-            float4 x4[kBnRows], d4[kBnRows];
+        for (long m0 = (long)blockIdx.x * rpb + rp; m0 < p.M; m0 += stride * kRows) {
+            float4 x4[kRows], d4[kRows];
 #pragma unroll
-            for (int u = 0; u < kBnRows; ++u) {
+            for (int u = 0; u < kRows; ++u) {
                 const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
                 x4[u] = bn_load_raw4<R16>(p.raw, mc * p.raw_cs + cg * 4);
             }
             if (vec_d) {
 #pragma unroll
-                for (int u = 0; u < kBnRows; ++u) {
+                for (int u = 0; u < kRows; ++u) {
                     const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
                     d4[u] = *reinterpret_cast<const float4*>(p.dout.p + mc * p.dout.cs + p.dout.coff + cg * 4);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < kBnRows; ++u) {
+            for (int u = 0; u < kRows; ++u) {
                 const long m = m0 + u * stride;
                 if (m >= p.M) break;
                 const float x[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};
@@ -613,6 +621,7 @@ inline void launch_bn_bwd_finalize(BnBwdParams& p, hipStream_t s) {
 // tensor's only reader's input-gradient launch; whole channel groups of four (the executor stores a gradient as bf16 only then)
 template <int MODE, int R16 = 0, int D16 = 0>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_in) {
+    constexpr int kRows = BnRows<R16>::value;                 // rows (independent loads per tensor) a thread keeps in flight
     DR_PIN_ARGS(p_in.dout.p, p_in.dout.cs, p_in.dout.coff, p_in.raw, p_in.raw_cs, p_in.M, p_in.C, p_in.relu, p_in.scale, p_in.shift, p_in.bnc, p_in.coef, p_in.draw, p_in.dres.p, p_in.dres.cs, p_in.dres.coff, p_in.dres_acc, p_in.draw_bf16, p_in.part, p_in.part_rows);
     BnBwdParams p = p_in;
     if (MODE == 0 && p.groups > 1) {                      // blockIdx.y = micro-batch group: its rows, its coefficients
@@ -687,16 +696,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_i
     const bool vec_d = full && (p.dout.coff % 4 == 0) && (p.dout.cs % 4 == 0);
     const bool vec_r = full && p.dres.p && (p.dres.coff % 4 == 0) && (p.dres.cs % 4 == 0);
     const long stride = (long)nblk * rpb;
-    for (long m0 = (long)bid * rpb + rp; m0 < p.M; m0 += stride * kBnRows) {
-        float4 x4[kBnRows], d4[kBnRows], r4[kBnRows];
+    for (long m0 = (long)bid * rpb + rp; m0 < p.M; m0 += stride * kRows) {
+        float4 x4[kRows], d4[kRows], r4[kRows];
 #pragma unroll
-        for (int u = 0; u < kBnRows; ++u) {
+        for (int u = 0; u < kRows; ++u) {
             const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
             x4[u] = bn_load_raw4<R16>(p.raw, mc * p.raw_cs + cg * 4);
         }
         if (D16) {
 #pragma unroll
-            for (int u = 0; u < kBnRows; ++u) {
+            for (int u = 0; u < kRows; ++u) {
                 const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
                 const dr_bf16x4 hd = *reinterpret_cast<const dr_bf16x4*>(reinterpret_cast<const __bf16*>(p.dout.p) + mc * p.dout.cs + p.dout.coff + cg * 4);
                 const dr_f32x4 fd = __builtin_convertvector(hd, dr_f32x4);
@@ -704,7 +713,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_i
             }
         } else if (vec_d) {
 #pragma unroll
-            for (int u = 0; u < kBnRows; ++u) {
+            for (int u = 0; u < kRows; ++u) {
                 const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
                 d4[u] = *reinterpret_cast<const float4*>(p.dout.p + mc * p.dout.cs + p.dout.coff + cg * 4);
             }
@@ -712,13 +721,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_i
         const bool acc_r = vec_r && p.dres_acc;                       // the residual gradient this pass adds to: same batch of loads
         if (acc_r) {
 #pragma unroll
-            for (int u = 0; u < kBnRows; ++u) {
+            for (int u = 0; u < kRows; ++u) {
                 const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
                 r4[u] = *reinterpret_cast<const float4*>(p.dres.p + mc * p.dres.cs + p.dres.coff + cg * 4);
             }
         }
 #pragma unroll
-        for (int u = 0; u < kBnRows; ++u) {
+        for (int u = 0; u < kRows; ++u) {
             const long m = m0 + u * stride;
             if (m >= p.M) break;
             const float x[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};

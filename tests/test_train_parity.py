@@ -223,6 +223,18 @@ def test_train_step_bf16_precision(be):
     h.close()
 
 
+def test_train_step_bf16_precision_with_fp32_storage(be, monkeypatch):
+    """The same criterion with every bf16 STORAGE decision of the training step switched off (DR_BF16_ACT / DRAW / RAW / GACT = 0:
+    single-reader activations and their gradients, dRaw and the raw outputs of BatchReNorm convs all fp32 in HBM) -- the paths the
+    defaults no longer take: the bf16 conv kernels' third epilogue copy reading an fp32 raw output, the fp32-raw BatchReNorm
+    passes beside bf16 matrix cores.  The switches are read when the handle is created."""
+    for k in ('DR_BF16_ACT', 'DR_BF16_DRAW', 'DR_BF16_RAW', 'DR_BF16_GACT'):
+        monkeypatch.setenv(k, '0')
+    cfg, params, ndm, poses, cfgs, coms = _case(1, 64, 4, 1 if be.name == 'emu' else 3)
+    h, _ = _bf16_step_check(be, cfg, params, ndm, poses, cfgs, coms)
+    h.close()
+
+
 def test_train_step_bf16_default_width_runs(be):
     """Regression (round-2 advisor finding): bf16 training at the default width F=128 with a per-rank batch of 3 failed in
     dr_backward with 'dgrad Conv_..: unsupported layout' -- the bf16-dRaw storage decision predicted the dgrad tile from all

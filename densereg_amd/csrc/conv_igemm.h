@@ -139,6 +139,10 @@ constexpr int conv_min_waves() { return BK_ == 64 ? 2 : (BM * BN >= 128 * 128 ? 
 // halves are summed through LDS after the K loop, wave wk = 0 runs the epilogue.  These layers ran on the 128x32 tile, whose
 // 32-column blocks re-stage the A tile three or five times and leave each wave ONE accumulator chain (0.27 of the MFMA
 // roofline); here A is staged once, 640 workgroups of M = 40960 fall 2.5 per CU, and every fragment pair feeds 3 or 5 MFMAs.
+// XB bit 1 (BF kernels; XB = 2 / 3): the kernel carries the two extra copies of the epilogue for bf16-stored raw outputs and
+// gradients (ConvParams::y_bf16 / bst_raw_bf16; conv_epilogue.inc) -- the launcher picks these instantiations for the training
+// launches that need them, everything else (the eval path, bias convs, plain input gradients) runs the one-copy kernels: with
+// the copies in every bf16 kernel the eval-mode forward lost 2-4 % (visit 16: one engine 15 540 -> 14 870 crops/s).
 // XB = 1 (BF kernels): the A operand is stored as bf16 (ConvParams::x_bf16) -- a compile-time variant, because a run-time
 // branch around the staging loads keeps hipcc from issuing them as one batch.
 // MF = 16 (narrow outputs in fp32: N = 65..80, 129..160; tiles 64x80, 64x144, 64x160): v_mfma_f32_16x16x4_f32 instead of 32x32x2 --
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256, (MF == 16 ? 5 : WK > 1 ? (BN > 96 ? 3 : 4) : c
     int ld_kc = 0, ld_dy = -pad, ld_dx = -pad, ld_tap = 0;
     const float* ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;      // wave-uniform cursors
     long ld_xo = (long)(ld_dy * p.W + ld_dx) * p.x_cs;                    // the same shift as an element offset (bf16 sources)
-    constexpr bool xb16 = XB != 0;
+    constexpr bool xb16 = (XB & 1) != 0;
     const float* ld_w = p.w;
     const bool ragged = (p.Cin & 3) != 0;                                  // uniform: Cin % 4 != 0
     int a_nv[T::kAIters];                                                  // only meaningful on ragged tiles
@@ -546,10 +550,10 @@ __global__ __launch_bounds__(256, (MF == 16 ? 5 : WK > 1 ? (BN > 96 ? 3 : 4) : c
     constexpr int EP_BATCH_ROWS = MF == 16 ? 4 : (BM * BN >= 128 * 128 || BK_ == 64) ? 16 : 8;
     constexpr int EP_TS = MF, EP_NR = NR;
     const int ep_lg = MF == 16 ? (lane >> 4) : lk, ep_lc = MF == 16 ? (lane & 15) : li;
-    if (BF != 0 && p.bst_raw_bf16) {                         // bf16 kernels: one copy of the epilogue per storage case (conv_epilogue.inc)
+    if ((XB & 2) != 0 && p.bst_raw_bf16) {                   // the XB = 2 / 3 kernels: one copy of the epilogue per storage case (conv_epilogue.inc)
         constexpr bool EP_Y16 = false, EP_B16 = true, EP_B16_CONST = true;
 #include "conv_epilogue.inc"
-    } else if (BF != 0 && p.y_bf16) {
+    } else if ((XB & 2) != 0 && p.y_bf16) {
         constexpr bool EP_Y16 = true, EP_B16 = false, EP_B16_CONST = false;
 #include "conv_epilogue.inc"
     } else {

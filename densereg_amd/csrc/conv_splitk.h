@@ -15,7 +15,7 @@
 
 namespace dr {
 
-template <int BF, int ABL = 0>
+template <int BF, int ABL = 0, int IO = 0>      // IO: with the epilogue copies for bf16-stored raw outputs / gradients (conv_igemm.h, XB bit 1)
 __global__ __launch_bounds__(256, 2) void conv_splitk_kernel(const ConvParams p) {
     DR_PIN_ARGS(p.x, p.x_cs, p.x_coff, p.Cin, p.B, p.H, p.W, p.ksize, p.w, p.Kp, p.Np, p.rowmask, p.zeros, p.gx);
     constexpr int BM = 32, BN = 32;
@@ -189,10 +189,10 @@ __global__ __launch_bounds__(256, 2) void conv_splitk_kernel(const ConvParams p)
     constexpr int EP_BATCH_ROWS = 16;     // two waves per SIMD by launch bounds: room for the whole column in one batch
     constexpr int EP_TS = 32, EP_NR = 16;
     const int ep_lg = lk, ep_lc = li;
-    if (BF != 0 && p.bst_raw_bf16) {                         // bf16 kernels: one copy of the epilogue per storage case (conv_epilogue.inc)
+    if (IO != 0 && p.bst_raw_bf16) {                         // one copy of the epilogue per storage case (conv_epilogue.inc)
         constexpr bool EP_Y16 = false, EP_B16 = true, EP_B16_CONST = true;
 #include "conv_epilogue.inc"
-    } else if (BF != 0 && p.y_bf16) {
+    } else if (IO != 0 && p.y_bf16) {
         constexpr bool EP_Y16 = true, EP_B16 = false, EP_B16_CONST = false;
 #include "conv_epilogue.inc"
     } else {

@@ -66,6 +66,11 @@ static void launch_cfg(const ConvParams& p_in, hipStream_t s) {
     } else {
         p.gx = (int)grid.x; p.gy = (int)grid.y;
         if constexpr (BF == 1) {
+            if (p.y_bf16 || p.bst_raw_bf16) {                  // the instantiations with the bf16-storage copies of the epilogue (XB bit 1)
+                if (p.x_bf16) DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK, 3>), grid, dim3(256), 0, s, p);
+                else DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK, 2>), grid, dim3(256), 0, s, p);
+                return;
+            }
             if (p.x_bf16) { DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK, 1>), grid, dim3(256), 0, s, p); return; }
         }
         DR_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0, BK, GL, BF, WK, 0>), grid, dim3(256), 0, s, p);
@@ -171,7 +176,8 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         dim3 grid(dr_ceil_div((int)M, 32), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, 32));
         ConvParams q = p;
         q.gx = (int)grid.x; q.gy = (int)grid.y;
-        if (p.bf16) DR_LAUNCH((conv_splitk_kernel<1>), grid, dim3(256), 0, s, q);
+        if (p.bf16 && (p.y_bf16 || p.bst_raw_bf16)) DR_LAUNCH((conv_splitk_kernel<1, 0, 1>), grid, dim3(256), 0, s, q);
+        else if (p.bf16) DR_LAUNCH((conv_splitk_kernel<1>), grid, dim3(256), 0, s, q);
         else DR_LAUNCH((conv_splitk_kernel<0>), grid, dim3(256), 0, s, q);
         return 0;
     }

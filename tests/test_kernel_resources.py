@@ -17,11 +17,12 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy():
     import kernel_resources
     rows = kernel_resources.collect()
     assert len(rows) > 60
-    # ONE exception, bounded: the bf16 64x128 kernel that stages an fp32-stored A operand, at its 96 registers, keeps five values
-    # of the prologue (lane / row coordinates) in 24 bytes of scratch across the K loop since its epilogue comes in three copies
-    # (conv_epilogue.inc: bf16-stored raw outputs) -- stored before the loop, reloaded behind it, nothing inside it (ISA read,
-    # profiles/r04_experiments.md section 9).  Anything more, or any other kernel, fails.
-    allowed = {'dr::conv_igemm_kernel<64, 128, 2, 2, 0, 16, 0, 1, 1, 0, 32>': 32}
+    # ONE exception, bounded: the bf16 64x128 kernel that stages an fp32-stored A operand, in the instantiation whose epilogue
+    # comes in three copies (XB = 2: bf16-stored raw outputs / gradients of the training step, conv_epilogue.inc), at its 96
+    # registers keeps five values of the prologue (lane / row coordinates) in 24 bytes of scratch across the K loop -- stored
+    # before the loop, reloaded behind it, nothing inside it (ISA read, profiles/r04_experiments.md section 9).  Anything more, or
+    # any other kernel -- the one-copy instantiations the eval path runs included -- fails.
+    allowed = {'dr::conv_igemm_kernel<64, 128, 2, 2, 0, 16, 0, 1, 1, 2, 32>': 32}
     spills = [(n, r['scratch']) for n, r in rows if r.get('scratch', 0) > allowed.get(n, 0)]
     assert not spills, spills
     occ = {n: r['occ'] for n, r in rows}

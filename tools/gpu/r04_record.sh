@@ -43,8 +43,9 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$G/prof_train -o train -- python $R/bench.py --steps 10 --warmup 5 $P > $R/$G/rocprof_train.log 2>&1
 DR_PIPELINE=1 DR_WGRAD_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$G/prof_train_inline -o train -- python $R/bench.py --steps 10 --warmup 5 $P > $R/$G/rocprof_train_inline.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$G/prof_infer -o infer -- python $R/bench.py --mode infer --replicas 1 --steps 10 --warmup 5 $P > $R/$G/rocprof_infer.log 2>&1
+DR_PIPELINE=1 DR_WGRAD_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$G/prof_train_bf16_inline -o train -- python $R/bench.py --precision bf16 --steps 10 --warmup 5 $P > $R/$G/rocprof_train_bf16_inline.log 2>&1
 cd $R
-for n in train train_inline infer; do
+for n in train train_inline infer train_bf16_inline; do
   db=$(ls $G/prof_$n/*_results.db 2>/dev/null | head -1)
   [ -n "$db" ] && python tools/rocpd_summary.py $db "bench.py (round 4, $n)" > $G/r04_${n}_kernel_stats.md && rm -rf $G/prof_$n
 done

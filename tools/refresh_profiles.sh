@@ -14,6 +14,7 @@ done
 cp $G/${R}_train_kernel_stats.md profiles/${R}_train_kernel_stats.md
 cp $G/${R}_train_inline_kernel_stats.md profiles/${R}_train_kernel_stats_inline.md
 cp $G/${R}_infer_kernel_stats.md profiles/${R}_infer_kernel_stats.md
+[ -s $G/${R}_train_bf16_inline_kernel_stats.md ] && cp $G/${R}_train_bf16_inline_kernel_stats.md profiles/${R}_train_kernel_stats_bf16_inline.md
 for n in train infer msra c5_bf16 c5_f32 train_bf16 torchrun allreduce train_g1; do
   [ -s $G/${R}_bench_$n.json ] && cp $G/${R}_bench_$n.json profiles/${R}_bench_$n.json
 done

@@ -1,5 +1,6 @@
 import os
 import sys
+import time
 import warnings
 
 import pytest
@@ -36,6 +37,59 @@ def gpu():
     return GpuBackend()
 
 
+# ---- order: the oracle-parity tests of the hot path first, executor-mode / reproducibility / stress loops last --------------------
+# (a run that is cut short -- the driver gives `pytest -m gpu` a wall-clock limit -- has then seen the parity evidence)
+_FILE_ORDER = ['test_abi.py', 'test_oracle_known_answers.py', 'test_gpu_configs.py', 'test_gpu_fullsize.py', 'test_trained_parity.py',
+               'test_train_parity.py', 'test_bench_shapes.py', 'test_forward_parity.py', 'test_bn_layer.py', 'test_pool.py',
+               'test_fused_tail.py', 'test_frontend.py', 'test_dataio.py', 'test_checkpoint.py', 'test_host_mirror.py',
+               'test_groups.py', 'test_data_parallel.py', 'test_configs_emu.py', 'test_kernel_resources.py', 'test_pipeline.py']
+
+
+def pytest_collection_modifyitems(config, items):
+    rank = {f: i for i, f in enumerate(_FILE_ORDER)}
+    pos = {id(it): i for i, it in enumerate(items)}
+
+    def key(it):
+        return (rank.get(os.path.basename(str(it.fspath)), len(_FILE_ORDER) - 1), pos[id(it)])
+    items.sort(key=key)
+
+
+# ---- one flushed line per test: the tail of a log that was cut names the last finished test and the running one -------------------
+def _live(config, line):
+    tr = config.pluginmanager.get_plugin('terminalreporter')
+    if tr is not None and os.environ.get('DR_TEST_LIVE', '1') != '0':
+        tr.ensure_newline()
+        tr.write_line(line)
+        try:
+            tr._tw.flush()
+        except Exception:
+            pass
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'pytest_live.log'), 'a') as f:
+            f.write(line + '\n')
+    except OSError:
+        pass
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_runtest_logstart(nodeid, location):
+    cfg = _live.config
+    if cfg is not None:
+        _live(cfg, '[%s start] %s' % (time.strftime('%H:%M:%S'), nodeid))
+
+
+def pytest_runtest_logreport(report):
+    cfg = _live.config
+    if cfg is None:
+        return
+    if report.when == 'call' or (report.when == 'setup' and report.outcome != 'passed'):
+        _live(cfg, '[%s %s] %s %.2fs' % (time.strftime('%H:%M:%S'), report.outcome, report.nodeid, report.duration))
+
+
+_live.config = None
+
+
 def pytest_terminal_summary(terminalreporter):
     """Which gradient bar the training-step tests applied on THIS box (tests/test_train_parity.py::_record_branch: the fp64
     autograd of the oracle needs host RAM; ``gpurun_out/`` does not travel back from the driver's box, the log does)."""
@@ -61,6 +115,7 @@ def pytest_terminal_summary(terminalreporter):
 
 
 def pytest_sessionstart(session):
+    _live.config = session.config
     # only the lines THIS session appends are summarised
     try:
         session.config._dr_branch_mark = os.path.getsize(os.path.join(ROOT, 'gpurun_out', 'test_branches.jsonl'))

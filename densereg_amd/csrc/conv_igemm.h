@@ -77,6 +77,9 @@ struct ConvParams {
     // values, so the layer normalises exactly what it stored; and the producer's raw output read back that way by bst mode.
     // y_bf16 together with bst_raw_bf16: the input gradient this launch is the only writer of (no res), stored as bf16 elements.
     int y_bf16, bst_raw_bf16;
+    // conv_x3.h: the same weights as three bf16 planes [Kp/16][tap][3][Np][16] (w = w0 + w1 + w2 to fp32 accuracy), or null.  With
+    // it the launcher may run the layer on the bf16 matrix cores with fp32-accurate products (launch_conv_igemm: conv_use_x3).
+    const void* w3;
 };
 
 // stateless keep bit for dropout(0.5): splitmix64 finaliser of (seed, element index)

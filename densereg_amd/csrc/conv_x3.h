@@ -1,0 +1,290 @@
+// conv_x3.h -- the implicit-GEMM convolution of conv_igemm.h with fp32-accurate products on the bf16 matrix cores.
+//
+// Same operator (tf.nn.conv2d + BatchReNorm/bias + ReLU + residual + dropout: network/slim/ops.py:219-299, network/um_v1.py:18-48),
+// same tensors (fp32 NHWC in, fp32 out), same fused epilogue (conv_epilogue.inc).  What changes is how a product a*b is formed:
+// every fp32 operand is split into three bf16 terms
+//        a = a0 + a1 + a2,   a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)        (round to nearest even)
+// which is EXACT to 2^-24 relative or better (three 8-bit significands cover fp32's 24 bits; each subtraction is exact), and
+//        a*b  ~=  a0*b0 + a0*b1 + a1*b0 + a0*b2 + a1*b1 + a2*b0
+// drops only the terms of relative size <= 2^-24 (a1*b2, a2*b1, a2*b2).  A bf16 x bf16 product is exact in fp32 and the matrix core
+// accumulates in fp32, so the result carries the rounding of an fp32 accumulation plus ~2^-23 per product: the same error class as
+// v_mfma_f32_32x32x2_f32 (tests: the unchanged 2e-5-of-range bar against the fp64 definition, and a direct comparison of both
+// kernels' errors).  Six v_mfma_f32_32x32x16_bf16 (32 cycles each, 16 k) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each,
+// 2 k) per 16 k: 192 matrix-core cycles instead of 512 -- the arithmetic lever of the 3x3 and wide 1x1 layers.
+//
+//   GEMM view as conv_igemm.h:  M = B*H*W, N = Cout, K = taps*Cin, K-tile = 16 input channels of one tap
+//   A: fp32 activations, split WHILE STAGED (one float4 per thread and 4 channels -> three 8-byte LDS writes)
+//   B: weights arrive pre-split from pack_all_kernel: bf16 [Kp/16][tap][3 planes][Np][16]
+//   LDS per stage and plane: [rows][16 bf16] = 32-byte rows of two 16-byte slots; lane (li = lane & 31, lk = lane >> 5) of a wave reads
+//   the 8 k of slot lk of row li with one ds_read_b128 = its whole operand of one MFMA.  Slot s of row r lives at s ^ ((r >> 3) & 1):
+//   every 16-lane group of a ds_read_b128 then covers all 64 banks once (MI355X_MICROARCH.md, LDS table).
+//   Block = 256 threads = 2 x 2 waves; wave tile (BM/2) x (BN/2) of 32x32 MFMA tiles.  128x128: 12 fragment reads feed 24 MFMAs.
+#pragma once
+#include "conv_igemm.h"
+
+namespace dr {
+
+// fp32 x 8 -> three planes of 8 bf16 (as float4 bit patterns); used by the weight packer on 1 element too
+__host__ __device__ static inline void x3_split4(const float4 v, uint2& h0, uint2& h1, uint2& h2) {
+    const dr_f32x4 f = {v.x, v.y, v.z, v.w};
+    const dr_bf16x4 b0 = __builtin_convertvector(f, dr_bf16x4);
+    const dr_f32x4 r1 = f - __builtin_convertvector(b0, dr_f32x4);
+    const dr_bf16x4 b1 = __builtin_convertvector(r1, dr_bf16x4);
+    const dr_f32x4 r2 = r1 - __builtin_convertvector(b1, dr_f32x4);
+    const dr_bf16x4 b2 = __builtin_convertvector(r2, dr_bf16x4);
+    h0 = __builtin_bit_cast(uint2, b0); h1 = __builtin_bit_cast(uint2, b1); h2 = __builtin_bit_cast(uint2, b2);
+}
+
+// LO = 1: the correction products in their own accumulator (below); LO = 0: all six products into one accumulator (measured variant)
+template <int BM, int BN, int LO = 1>
+__global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvParams p) {
+    constexpr int WM = 2, WN = 2, WK = 1, MF = 32, ABL = 0;
+    constexpr int kWTM = BM / WM, kWTN = BN / WN, kTM = kWTM / 32, kTN = kWTN / 32;
+    static_assert(kWTM % 32 == 0 && kWTN % 32 == 0, "wave tile of whole 32x32 MFMA tiles");
+    constexpr int CK = 16;                                   // input channels per K-tile
+    constexpr int kAIters = (BM * 4 + 255) / 256;            // float4 units (4 channels of a row) per thread
+    constexpr int kBUnits = 3 * BN * 2;                      // 16-byte units of the three weight planes
+    constexpr int kBIters = (kBUnits + 255) / 256;
+    // one LDS object per stage (conv_igemm.h: the wait-count insertion tells stages apart by object); [plane][row][2 slots] of 16 bytes
+    __shared__ __attribute__((aligned(16))) float4 As0[3][BM][2];
+    __shared__ __attribute__((aligned(16))) float4 As1[3][BM][2];
+    __shared__ __attribute__((aligned(16))) float4 Bs0[3][BN][2];
+    __shared__ __attribute__((aligned(16))) float4 Bs1[3][BN][2];
+#define DR_AS(stage) ((stage) ? As1 : As0)
+#define DR_BS(stage) ((stage) ? Bs1 : Bs0)
+
+    DR_PIN_ARGS(p.x, p.x_cs, p.x_coff, p.Cin, p.B, p.H, p.W, p.ksize, p.w3, p.Kp, p.Np, p.rowmask, p.zeros, p.nfast, p.gx, p.gy, p.Ng);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wk = 0;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int HW = p.H * p.W;
+    const int M = p.B * HW;
+    // workgroup -> tile: the XCD-aware mapping of conv_igemm.h (row blocks of one XCD contiguous, N blocks of a row block back to back)
+    const int gx = p.gx, gy = p.gy;
+    int mblk = blockIdx.x, nblk = blockIdx.y;
+    if (p.nfast && gy > 1) {
+        const int L = blockIdx.y * gx + blockIdx.x, nN = gy;
+        if ((gx & 7) == 0) { const int s = L >> 3; mblk = (L & 7) * (gx >> 3) + s / nN; nblk = s % nN; }
+        else { mblk = L / nN; nblk = L % nN; }
+    } else if ((gx & 7) == 0) {
+        mblk = (blockIdx.x & 7) * (gx >> 3) + (blockIdx.x >> 3);
+    }
+    const int m0 = mblk * BM;
+    const int n0 = nblk * BN;
+    const int taps = p.ksize * p.ksize;
+    const int KT = (p.Kp + CK - 1) / CK;
+    const int T_total = taps * KT;
+    const int pad = p.ksize / 2;
+
+    // ---- per-thread loader bookkeeping: unit (row, q) = channels 4q..4q+3 of the K-tile for output pixel m0 + row ------------------
+    int a_row[kAIters], a_q[kAIters];
+    unsigned a_off[kAIters], a_taps[kAIters];
+    const bool pow2 = (p.W & (p.W - 1)) == 0 && (HW & (HW - 1)) == 0;
+    const int w_shift = __builtin_ctz((unsigned)p.W);
+#pragma unroll
+    for (int i = 0; i < kAIters; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx >> 2;
+        a_row[i] = row;
+        a_q[i] = idx & 3;
+        const int m = m0 + row;
+        bool ok = row < BM && m < M;
+        if (ok && p.rowmask) ok = !(p.rowmask[m] < p.mask_thresh);
+        const int mm = ok ? m : 0;
+        int y, x;
+        if (pow2) {
+            const int rem = mm & (HW - 1);
+            y = rem >> w_shift; x = rem & (p.W - 1);
+        } else {
+            const int rem = mm % HW;
+            y = rem / p.W; x = rem % p.W;
+        }
+        unsigned mask = 1u;
+        if (p.ksize == 3) {
+            const unsigned cols = (x > 0 ? 1u : 0u) | 2u | (x < p.W - 1 ? 4u : 0u);
+            mask = (y > 0 ? cols : 0u) | (cols << 3) | (y < p.H - 1 ? cols << 6 : 0u);
+        }
+        a_taps[i] = ok ? mask : 0u;
+        a_off[i] = ok ? (unsigned)((long)m * p.x_cs + p.x_coff + a_q[i] * 4) : 0u;
+    }
+    // weight planes: unit u = (plane, row, slot), 16 bytes = 8 bf16; the three planes of a K-tile are Np * 16 bf16 apart
+    const __bf16* const w3 = reinterpret_cast<const __bf16*>(p.w3);
+    unsigned b_off[kBIters]; int b_lds[kBIters]; bool b_ok[kBIters];
+#pragma unroll
+    for (int i = 0; i < kBIters; ++i) {
+        const int u = tid + i * 256;
+        const int pl = u / (BN * 2), within = u % (BN * 2), row = within >> 1, slot = within & 1;
+        b_ok[i] = u < kBUnits && n0 + row < p.Np;
+        b_off[i] = (unsigned)((pl * p.Np + n0 + row) * 16 + slot * 8);
+        b_lds[i] = (pl * BN + row) * 2 + (slot ^ ((row >> 3) & 1));
+    }
+    const long w_tile = 3l * p.Np * 16;                                    // bf16 elements per (chunk, tap)
+
+    float4 a_reg[kAIters];
+    float4 b_reg0, b_reg1, b_reg2;                                          // (scalars: hipcc keeps a float4[3] refilled inside the unrolled K loop in scratch)
+    static_assert(kBIters <= 3, "weight loader mapping");
+    int ld_kc = 0, ld_dy = -pad, ld_dx = -pad, ld_tap = 0;
+    const float* ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;
+    const __bf16* ld_w = w3;
+    int a_nv[kAIters];
+    auto load_tile = [&]() __attribute__((always_inline)) {
+        const bool tail = ld_kc + CK > p.Cin;                              // uniform: this chunk crosses Cin
+#pragma unroll
+        for (int i = 0; i < kAIters; ++i) {
+            bool ok = (a_taps[i] >> ld_tap) & 1u;
+            int nv = 4;
+            if (tail) {
+                const int left = p.Cin - (ld_kc + a_q[i] * 4);
+                nv = left < 0 ? 0 : (left > 4 ? 4 : left);
+                ok = ok && nv > 0;
+            }
+            a_reg[i] = *reinterpret_cast<const float4*>(ok ? ld_x + ld_kc + a_off[i] : p.zeros);
+            a_nv[i] = ok ? nv : 4;
+        }
+#define X3_LOAD_B(i) *reinterpret_cast<const float4*>(b_ok[i] ? reinterpret_cast<const void*>(ld_w + b_off[i]) : reinterpret_cast<const void*>(p.zeros))
+        b_reg0 = X3_LOAD_B(0);
+        if constexpr (kBIters > 1) b_reg1 = X3_LOAD_B(1);
+        if constexpr (kBIters > 2) b_reg2 = X3_LOAD_B(2);
+#undef X3_LOAD_B
+        ++ld_tap;
+        if (++ld_dx > pad) { ld_dx = -pad; ++ld_dy; }
+        if (ld_tap == taps) {
+            ld_tap = 0;
+            ld_dy = ld_dx = -pad;
+            ld_kc += CK;
+        }
+        ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;
+        ld_w += w_tile;
+    };
+    const bool ragged = (p.Cin & 3) != 0;
+    auto store_tile = [&](const int buf, const bool was_tail) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < kAIters; ++i) {
+            const int r = a_row[i], q = a_q[i];
+            if (BM * 4 < 256 * kAIters && r >= BM) continue;
+            float4 v = a_reg[i];
+            if (ragged && was_tail) {
+                const int nv = a_nv[i];
+                v.y = nv > 1 ? v.y : 0.f;
+                v.z = nv > 2 ? v.z : 0.f;
+                v.w = nv > 3 ? v.w : 0.f;
+            }
+            uint2 h0, h1, h2;
+            x3_split4(v, h0, h1, h2);
+            const int slot = (q >> 1) ^ ((r >> 3) & 1);
+            uint2* d0 = reinterpret_cast<uint2*>(&DR_AS(buf)[0][r][slot]) + (q & 1);
+            uint2* d1 = reinterpret_cast<uint2*>(&DR_AS(buf)[1][r][slot]) + (q & 1);
+            uint2* d2 = reinterpret_cast<uint2*>(&DR_AS(buf)[2][r][slot]) + (q & 1);
+            *d0 = h0; *d1 = h1; *d2 = h2;
+        }
+        float4* const bs = &DR_BS(buf)[0][0][0];
+        if (kBUnits % 256 == 0 || tid < kBUnits) bs[b_lds[0]] = b_reg0;
+        if constexpr (kBIters > 1) { if (kBUnits % 256 == 0 || tid + 256 < kBUnits) bs[b_lds[1]] = b_reg1; }
+        if constexpr (kBIters > 2) { if (kBUnits % 256 == 0 || tid + 512 < kBUnits) bs[b_lds[2]] = b_reg2; }
+    };
+
+    // Two accumulators per output tile: `acc` takes the leading products a0*b0, `lo` the five correction products (each <= 2^-8 of
+    // the leading one).  Added to ONE accumulator every correction would round at the magnitude of the running sum -- six roundings
+    // per k instead of one, which measured 4-7x the fp32 kernel's error on operands spread over many binades; in its own accumulator
+    // the corrections round at 2^-8 of that magnitude and join the sum once, after the K loop.
+    using AccT = dr_f32x16;
+    constexpr int NR = 16;
+    AccT acc[kTM][kTN], lo[LO ? kTM : 1][LO ? kTN : 1];
+#pragma unroll
+    for (int i = 0; i < kTM; ++i)
+#pragma unroll
+        for (int j = 0; j < kTN; ++j)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { acc[i][j][r] = 0.f; if constexpr (LO) lo[i][j][r] = 0.f; }
+
+    const bool tail0 = CK > p.Cin;
+    load_tile();
+    store_tile(0, tail0);
+    __syncthreads();
+
+    const int lk = lane >> 5;
+    const int li = lane & 31;
+    const int fslot = lk ^ ((li >> 3) & 1);                                // this lane's LDS slot of every row it reads (rows = 32*t + li)
+    auto k_tile = [&](const int buf, const bool more) __attribute__((always_inline)) {
+        const bool was_tail = ld_kc + CK > p.Cin;                          // of the tile being fetched now
+        if (more) load_tile();
+        // fragments are read plane by plane, the planes 2 first: their registers are reused by the planes 1 (eight fragments live, not twelve)
+        float4 a0[kTM], b0[kTN], ax[kTM], bx[kTN];
+        auto& LOACC = *reinterpret_cast<AccT(*)[kTM][kTN]>(LO ? &lo[0][0] : &acc[0][0]);
+#define X3_READ_A(d, pl) _Pragma("unroll") for (int i = 0; i < kTM; ++i) d[i] = DR_AS(buf)[pl][wm * kWTM + i * 32 + li][fslot]
+#define X3_READ_B(d, pl) _Pragma("unroll") for (int j = 0; j < kTN; ++j) d[j] = DR_BS(buf)[pl][wn * kWTN + j * 32 + li][fslot]
+#define X3_MMA(c, a, b)                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < kTM; ++i) _Pragma("unroll") for (int j = 0; j < kTN; ++j)                              \
+        c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dr_bf16x8, a[i]), __builtin_bit_cast(dr_bf16x8, b[j]), c[i][j], 0, 0, 0)
+        X3_READ_A(a0, 0); X3_READ_B(b0, 0); X3_READ_A(ax, 2); X3_READ_B(bx, 2);
+        X3_MMA(LOACC, ax, b0);                                                // a2*b0
+        X3_MMA(LOACC, a0, bx);                                                // a0*b2
+        X3_READ_A(ax, 1); X3_READ_B(bx, 1);
+        X3_MMA(acc, a0, b0);                                               // the leading products run while the planes 1 arrive
+        X3_MMA(LOACC, ax, bx);                                                // a1*b1
+        X3_MMA(LOACC, ax, b0);                                                // a1*b0
+        X3_MMA(LOACC, a0, bx);                                                // a0*b1
+#undef X3_READ_A
+#undef X3_READ_B
+#undef X3_MMA
+        if (more) store_tile(buf ^ 1, was_tail);
+        __syncthreads();
+    };
+    const int T_pairs = T_total & ~1;
+    for (int t = 0; t < T_pairs; t += 2) {
+        k_tile(0, true);
+        k_tile(1, t + 2 < T_total);
+    }
+    if (T_total & 1) k_tile(0, false);
+#pragma unroll
+    for (int i = 0; i < kTM; ++i)
+#pragma unroll
+        for (int j = 0; j < kTN; ++j) { if constexpr (LO) acc[i][j] += lo[i][j]; }
+
+    // ---- epilogue: conv_epilogue.inc (the fp32 copy) -------------------------------------------------------------------------------
+    double s1[kTN], s2[kTN];
+#pragma unroll
+    for (int j = 0; j < kTN; ++j) s1[j] = s2[j] = 0.0;
+    constexpr int EP_TM = kTM, EP_TN = kTN;
+    const int ep_m0 = m0 + wm * kWTM, ep_n0 = n0 + wn * kWTN;
+    const unsigned ep_rows = 0xFFFFu;
+    constexpr int EP_BATCH_ROWS = 8;
+    constexpr int EP_TS = MF, EP_NR = NR;
+    const int ep_lg = lk, ep_lc = li;
+    {
+        constexpr bool EP_Y16 = false, EP_B16 = false, EP_B16_CONST = false;
+#include "conv_epilogue.inc"
+    }
+    if (p.stat_part) {
+        double* red = reinterpret_cast<double*>(&As0[0][0][0]);            // the operand tiles are dead: the K loop ended on a barrier
+        static_assert(sizeof(As0) >= sizeof(double) * 2 * WM * BN, "stat scratch does not fit the operand tile");
+#pragma unroll
+        for (int j = 0; j < kTN; ++j) {
+            double a = s1[j], b = s2[j];
+            a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 32);
+            if (ep_lg == 0) {
+                const int col = wn * kWTN + j * MF + ep_lc;
+                red[(0 * WM + wm) * BN + col] = a;
+                red[(1 * WM + wm) * BN + col] = b;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * BN; e += 256) {
+            const int which = e / BN, col = e % BN, n = n0 + col;
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + col];
+            if (n < p.Cout) p.stat_part[((long)which * p.Cout + n) * gx + mblk] = t;
+        }
+    }
+    (void)wk; (void)WK;
+}
+
+#undef DR_AS
+#undef DR_BS
+
+}  // namespace dr

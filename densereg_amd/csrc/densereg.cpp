@@ -4,9 +4,11 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <mutex>
 
 #include "conv_igemm.h"
 #include "conv_splitk.h"
+#include "conv_x3.h"
 #include "conv_wgrad.h"
 #include "conv_wgrad_bf16.h"
 #include "conv_wgrad_tr.h"
@@ -91,14 +93,17 @@ static int g_dbg_bf16 = 0;           // test/bench hook (dr_dbg_force_bf16): dr_
 static int g_dbg_bf16_storage = 0;   // test hook (dr_dbg_force_bf16_storage): bf16-stored x / g / draw in the debug entries
 
 static int conv_tile_heuristic(const ConvParams& p);
+bool conv_use_x3(const ConvParams& p);
 static int tile_rows_of(int t) {
     if (t == KID_CONV_SPLITK) return 32;
+    if (t == KID_CONV_X3) return 128;
     return (t == KID_CONV_64x128 || t == KID_CONV_64x64 || t == KID_CONV_64x64_K64 || t == KID_CONV_64x96 || t == KID_CONV_64x160 ||
             (t >= KID_CONV16_64x80 && t <= KID_CONV16_64x160)) ? 64 : 128;
 }
 // tile shape for a problem (shared by the launcher and the profiler labels)
 int conv_tile_id(const ConvParams& p) {
     if (g_force_tile >= 0) return g_force_tile;
+    if (conv_use_x3(p)) return KID_CONV_X3;
     const int t = conv_tile_heuristic(p);
     // micro-batch groups: a workgroup's rows must lie in one group (per-group statistics rows, per-group coefficients) -- where
     // the preferred tile straddles the boundaries (2x2 layers: 4 rows per crop) the 32-row split-K kernel takes the launch
@@ -154,6 +159,21 @@ static int conv_tile_heuristic(const ConvParams& p) {
     return KID_CONV_128x32;
 }
 
+// conv_x3.h (fp32-accurate products on the bf16 matrix cores, 128x128 tile): where it is used.  DR_CONV_X3: 0 = never,
+// 1 = the measured rule (default), 2 = wherever the kernel can run (tests)
+static int g_dbg_x3 = -1;            // test/bench hook (dr_dbg_force_x3): overrides DR_CONV_X3
+bool conv_use_x3(const ConvParams& p) {
+    static const int env = [] { const char* e = getenv("DR_CONV_X3"); return e ? atoi(e) : 1; }();
+    const int mode = g_dbg_x3 >= 0 ? g_dbg_x3 : env;
+    if (mode <= 0 || !p.w3 || p.bf16 || p.x_bf16 || p.y_bf16 || p.bst_raw_bf16 || g_force_tile >= 0) return false;
+    if (p.grp_rows > 0 && p.grp_rows % 128 != 0) return false;
+    if (mode >= 2) return true;
+    const long M = (long)p.B * p.H * p.W;
+    const int ncols = p.Ng > 0 ? p.Ng : p.Np;
+    // whole 128-column blocks (a 160-column layer would compute 256), and a grid of at least two workgroups per CU
+    return ncols % 128 == 0 && dr_ceil_div((int)M, 128) * (long)(ncols / 128) >= 512 && (long)p.ksize * p.ksize * p.Kp >= 128;
+}
+
 // output rows per workgroup of the tile a problem gets
 int conv_tile_rows(const ConvParams& p) { return tile_rows_of(conv_tile_id(p)); }
 // rows of ConvParams::stat_part the launch writes = workgroups along M of the chosen tile
@@ -170,6 +190,17 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     if (p.y_bf16 && !p.bst_raw_bf16 && (p.scale || p.shift || p.relu || p.res || p.drop || p.drop_rng || p.bst_raw || p.out_rowmask)) return -1;
     if (p.y_bf16 && p.bst_raw_bf16 && p.res) return -1;                  // a bf16-stored dOut has ONE writer
     if (p.bst_raw_bf16 && (!p.bst_raw || p.bst_act || p.scale || p.shift || p.relu || p.drop || p.drop_rng)) return -1;
+    if (conv_tile_id(p) == KID_CONV_X3) {
+        static const int nfast = [] { const char* e = getenv("DR_CONV_NFAST"); return (e && e[0] == '0') ? 0 : 1; }();
+        ConvParams q = p;
+        q.nfast = nfast;
+        dim3 grid(dr_ceil_div((int)M, 128), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, 128));
+        q.gx = (int)grid.x; q.gy = (int)grid.y;
+        static const int variant = [] { const char* e = getenv("DR_X3_VARIANT"); return e ? atoi(e) : 0; }();
+        if (variant == 1 || g_dbg_x3 == 3) DR_LAUNCH((conv_x3_kernel<128, 128, 0>), grid, dim3(256), 0, s, q);
+        else DR_LAUNCH((conv_x3_kernel<128, 128, 1>), grid, dim3(256), 0, s, q);
+        return 0;
+    }
     if (conv_tile_id(p) == KID_CONV_SPLITK) {
         if (p.bf16 && p.Kp % 32) return -1;
         if (p.x_bf16) return -1;                                          // the split-K kernel stages fp32 only
@@ -290,7 +321,22 @@ __global__ __launch_bounds__(256) void pack_weights_T_kernel(const float* w, flo
 // Every layer's forward and dgrad packing in ONE launch (292 separate ~3 us launches per optimizer step otherwise).
 // Segment s covers workgroups [first_block, next first_block) of 256 packed elements each.
 struct PackSeg { long w_off; long dst_off; int taps, Cin, Cout, Kp, Np, transposed, first_block; };
-__global__ __launch_bounds__(256) void pack_all_kernel(const float* flat, float* wp, float* wpT, const PackSeg* segs, int nseg) {
+// conv_x3.h: element i of an fp32 packed buffer [chunk][tap][Np][16] as three bf16 planes [chunk][tap][3][Np][16]
+__device__ __forceinline__ void x3_store_planes(__bf16* w3, long i, int Np, float v) {
+    const long tile = (long)Np * 16, b = i / tile, within = i % tile;
+    const __bf16 h0 = (__bf16)v;
+    const float r1 = v - (float)h0;
+    const __bf16 h1 = (__bf16)r1;
+    const __bf16 h2 = (__bf16)(r1 - (float)h1);
+    __bf16* d = w3 + (b * 3) * tile + within;
+    d[0] = h0; d[tile] = h1; d[2 * tile] = h2;
+}
+// a whole fp32 packed buffer -> planes (debug entry points; the handle's weights go through pack_all_kernel)
+__global__ __launch_bounds__(256) void pack_x3_kernel(const float* wp, __bf16* w3, long total, int Np) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) x3_store_planes(w3, i, Np, wp[i]);
+}
+
+__global__ __launch_bounds__(256) void pack_all_kernel(const float* flat, float* wp, float* wpT, const PackSeg* segs, int nseg, __bf16* wp3, __bf16* wp3T) {
     int lo = 0, hi = nseg - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -322,9 +368,13 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* flat, float*
     const int t = int((i / (16l * sg.Np)) % sg.taps);
     const int k = int(i / (16l * sg.Np * sg.taps)) * 16 + kk;
     if (!sg.transposed) {
-        wp[sg.dst_off + i] = (k < sg.Cin && n < sg.Cout) ? w[((long)t * sg.Cin + k) * sg.Cout + n] : 0.f;
+        const float v = (k < sg.Cin && n < sg.Cout) ? w[((long)t * sg.Cin + k) * sg.Cout + n] : 0.f;
+        wp[sg.dst_off + i] = v;
+        if (wp3) x3_store_planes(wp3 + 3 * sg.dst_off, i, sg.Np, v);
     } else {                                                    // dgrad: k = cout, n = cin, taps flipped
-        wpT[sg.dst_off + i] = (k < sg.Cout && n < sg.Cin) ? w[((long)(sg.taps - 1 - t) * sg.Cin + n) * sg.Cout + k] : 0.f;
+        const float v = (k < sg.Cout && n < sg.Cin) ? w[((long)(sg.taps - 1 - t) * sg.Cin + n) * sg.Cout + k] : 0.f;
+        wpT[sg.dst_off + i] = v;
+        if (wp3T) x3_store_planes(wp3T + 3 * sg.dst_off, i, sg.Np, v);
     }
 }
 
@@ -450,7 +500,21 @@ struct Builder {
             int nc = 0;
             for (int i = first_op; i <= fr.last_op; ++i)
                 if (h->ops[i].kind == OP_CONV && nc < 24) fr.conv[nc++] = h->ops[i].conv;
-            if (nc == 24) h->fused.push_back(fr);
+            // hg_tail_eval_kernel hard-codes what `residual` emits today -- eight identity-skip modules of 1x1 F->F/2, 3x3 F/2->F/2,
+            // 1x1 F/2->F, BatchReNorm + ReLU on every conv, on F input channels: a region of any other shape stays unfused
+            const int F = h->cfg.num_fea;
+            bool shape_ok = nc == 24 && ins.C == F && lower3.C == F;
+            for (int i = 0; shape_ok && i < 24; ++i) {
+                const ConvLayer& cl = h->convs[fr.conv[i]];
+                const int k3 = i % 3;
+                shape_ok = cl.bn && cl.relu && cl.stride == 1 && cl.k == (k3 == 1 ? 3 : 1) && cl.cin == (k3 == 0 ? F : F / 2) &&
+                           cl.cout == (k3 == 2 ? F : F / 2);
+            }
+            for (int i = first_op; shape_ok && i <= fr.last_op; ++i) {      // the third conv of a module adds the module's own input
+                const Op& o = h->ops[i];
+                if (o.kind == OP_CONV && h->convs[o.conv].k == 1 && h->convs[o.conv].cout == F) shape_ok = o.in2.valid() && o.in2.C == F;
+            }
+            if (shape_ok) h->fused.push_back(fr);
         }
         cur_lane = parent;
         if (split) edge(OP_JOIN, parent, child);
@@ -564,11 +628,11 @@ void add_param(dr_handle* h, const std::string& name, std::initializer_list<int>
 #include "pipeline.inc"
 
 static void free_all(dr_handle* h) {
-    pipeline_drain(h);
+    (void)pipeline_drain(h);
     if (h->slot[0].act_arena) bind_slot(h, 0);             // the working fields name slot 0's buffers again: freed below
     free_slot1(h);
     for (void* p : {(void*)h->flat_param, (void*)h->flat_grad, (void*)h->adam_m, (void*)h->adam_v, (void*)h->flat_state, (void*)h->flat_state_next,
-                    (void*)h->shadow, (void*)h->wp, (void*)h->wpT, (void*)h->fold, (void*)h->bnc,
+                    (void*)h->shadow, (void*)h->wp, (void*)h->wpT, (void*)h->wp3, (void*)h->wp3T, (void*)h->fold, (void*)h->bnc,
                     (void*)h->act_arena, (void*)h->grad_arena, (void*)h->scratch, (void*)h->tiny, (void*)h->tiny_ext, (void*)h->zeros,
                     (void*)h->losses, (void*)h->reg_segs, (void*)h->loss_acc, (void*)h->bn_coef, (void*)h->wg_partial, (void*)h->fold_dev, h->pack_dev, h->zero_dev,
                     (void*)h->g_keep_arena, (void*)h->pool_arg_arena, (void*)h->group_dev, (void*)h->bn_flags})
@@ -583,7 +647,7 @@ static void free_all(dr_handle* h) {
         if (h->stat_part_l[l]) rt::dfree(h->stat_part_l[l]);
         if (h->stat_part2_l[l]) rt::dfree(h->stat_part2_l[l]);
     }
-    if (h->wg_stream) { rt::sync_stream(h->wg_stream); rt::stream_destroy(h->wg_stream); rt::event_destroy(h->wg_ready); rt::event_destroy(h->wg_done); }
+    if (h->wg_stream) { if (rt::sync_stream(h->wg_stream) == 0) rt::stream_destroy(h->wg_stream); rt::event_destroy(h->wg_ready); rt::event_destroy(h->wg_done); }
     for (auto& e : h->lane_ev) rt::event_destroy(e);
     for (auto& g : h->graphs) rt::graph_destroy(g.g);
     rt::stream_destroy(h->cap_stream);
@@ -676,6 +740,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
     alloc_f(h->flat_param, nt);
     alloc_f(h->flat_state, ns);
     alloc_f(h->wp, nwp);
+    h->wp3 = (__bf16*)rt::dmalloc(std::max<size_t>(nwp, 1) * 3 * sizeof(__bf16)); ok = ok && h->wp3;      // conv_x3.h
     alloc_f(h->fold, nfold * (cfg->training ? (size_t)kMaxGroups : 1));      // training: one copy per micro-batch group (dr_set_groups)
     alloc_f(h->act_arena, h->n_act);
     alloc_f(h->scratch, h->n_scratch);
@@ -743,6 +808,7 @@ int dr_create(const dr_config* cfg, dr_handle** out) {
         alloc_f(h->shadow, nsh);
         alloc_f(h->flat_state_next, ns);
         alloc_f(h->wpT, nwpT);
+        h->wp3T = (__bf16*)rt::dmalloc(std::max<size_t>(nwpT, 1) * 3 * sizeof(__bf16)); ok = ok && h->wp3T;
         alloc_f(h->bnc, nbnc * (size_t)kMaxGroups);
         h->n_gact = nact;
         alloc_f(h->grad_arena, nact);
@@ -851,7 +917,7 @@ static float* param_dev_ptr(dr_handle* h, const ParamInfo& p) {
 
 int dr_load_param(dr_handle* h, const char* name, const float* host, size_t count) {
     if (!h || !name || !host) return DR_E_INVALID;
-    pipeline_drain(h);
+    if (pipeline_drain(h)) DR_FAIL(h, DR_E_DEVICE, "a micro-step slot's stream did not drain");
     const ParamInfo* p = find_param(h, name);
     if (!p) {
         int slot = 0;
@@ -890,7 +956,7 @@ int dr_load_param(dr_handle* h, const char* name, const float* host, size_t coun
 
 int dr_read_param(dr_handle* h, const char* name, float* host, size_t count) {
     if (!h || !name || !host) return DR_E_INVALID;
-    pipeline_drain(h);
+    if (pipeline_drain(h)) DR_FAIL(h, DR_E_DEVICE, "a micro-step slot's stream did not drain");
     const ParamInfo* p = find_param(h, name);
     if (!p) {
         int slot = 0;
@@ -955,7 +1021,8 @@ static int repack_weights(dr_handle* h, hipStream_t s) {
     }
     if (h->pack_blocks > 0)
         DR_LAUNCH(pack_all_kernel, dim3(h->pack_blocks), dim3(256), 0, s, (const float*)h->flat_param, h->wp, h->wpT,
-                  (const PackSeg*)h->pack_dev, h->pack_nseg);
+                  (const PackSeg*)h->pack_dev, h->pack_nseg, h->precision == 0 ? h->wp3 : (__bf16*)nullptr,
+                  h->precision == 0 ? h->wp3T : (__bf16*)nullptr);
     DR_CHECK_LAUNCH(h);
     return DR_OK;
 }
@@ -976,7 +1043,7 @@ int dr_set_precision(dr_handle* h, int precision) {
     if (!h) return DR_E_INVALID;
     if (precision != DR_PREC_F32 && precision != DR_PREC_BF16) DR_FAIL(h, DR_E_INVALID, "dr_set_precision: unknown precision %d", precision);
     if (precision != h->precision) {
-        pipeline_drain(h);
+        if (pipeline_drain(h)) DR_FAIL(h, DR_E_DEVICE, "a micro-step slot's stream did not drain");
         rt::sync_stream(nullptr);
         if (h->pack_dev) { rt::dfree(h->pack_dev); h->pack_dev = nullptr; }     // the packing table depends on the element type
         h->precision = precision;
@@ -1002,7 +1069,7 @@ int dr_set_fusion(dr_handle* h, int on) {
 int dr_finalize_params(dr_handle* h, dr_stream stream) {
     if (!h) return DR_E_INVALID;
     DR_ENTER(h);
-    pipeline_drain(h);
+    if (pipeline_drain(h)) DR_FAIL(h, DR_E_DEVICE, "a micro-step slot's stream did not drain");
     hipStream_t s = (hipStream_t)stream;
     int rc = repack_weights(h, s);
     if (rc) return rc;
@@ -1130,6 +1197,7 @@ static int run_conv_eval(dr_handle* h, const Op& op, int B, hipStream_t s) {
     p.x = op.in.t->p; p.x_cs = op.in.t->cs; p.x_coff = op.in.coff; p.Cin = op.in.C;
     p.B = B; p.H = c.H; p.W = c.W; p.ksize = c.k;
     p.w = h->wp + c.wp_off; p.Kp = c.Kp; p.Np = c.Np;
+    p.w3 = h->precision == 0 && h->wp3 ? h->wp3 + 3 * c.wp_off : nullptr;
     if (h->precision == 1) { p.bf16 = 1; p.Kp = dr_round_up(c.cin, 32); }
     p.y = op.out.t->p; p.y_cs = op.out.t->cs; p.y_coff = op.out.coff; p.Cout = c.cout;
     if (c.bn) { p.scale = h->fold + c.fold_off; p.shift = h->fold + c.fold_off + c.cout; }
@@ -1201,13 +1269,19 @@ static int run_fused_region(dr_handle* h, const FusedRegion& fr, int B, hipStrea
     const size_t lds = (size_t)hg_fused_lds_floats(p.F) * sizeof(float);
     // (four waves per workgroup, one per SIMD; a variant with eight -- the 8x8 levels' row tiles split over two waves per SIMD --
     // measured equal, profiles/r04_experiments.md, and is not instantiated)
-    static const bool lds_ok = [] {
-        bool ok = true;
-        ok = ok && rt::allow_dyn_lds((const void*)hg_tail_eval_kernel<96, 4>, (size_t)hg_fused_lds_floats(96) * sizeof(float));
-        ok = ok && rt::allow_dyn_lds((const void*)hg_tail_eval_kernel<128, 4>, (size_t)hg_fused_lds_floats(128) * sizeof(float));
-        return ok;
-    }();
-    if (!lds_ok) DR_FAIL(h, DR_E_DEVICE, "fused hourglass bottom: %zu bytes of LDS per workgroup refused", lds);
+    // the > 64 KB dynamic-LDS attribute is a property of (kernel, device): asked once per device, and only for the F that needs it
+    if (lds > 64 * 1024) {
+        static std::mutex mu;
+        static std::map<std::pair<int, int>, bool> granted;
+        std::lock_guard<std::mutex> lk(mu);
+        const auto key = std::make_pair(h->cfg.device, p.F);
+        auto it = granted.find(key);
+        if (it == granted.end()) {
+            const void* fn = p.F == 96 ? (const void*)hg_tail_eval_kernel<96, 4> : (const void*)hg_tail_eval_kernel<128, 4>;
+            it = granted.emplace(key, rt::allow_dyn_lds(fn, lds)).first;
+        }
+        if (!it->second) return DR_E_UNSUPPORTED;              // (the caller falls back to the unfused ops)
+    }
     ProfScope ps(h, s, KID_HG_FUSED, flops, 4.0 * B * p.F * (256.0 + 64.0));
     switch (p.F) {                                              // (hg_fused_supported: multiples of 32 up to 128)
         case 32: DR_LAUNCH((hg_tail_eval_kernel<32, 4>), dim3(B), dim3(256), lds, s, p); break;
@@ -1225,7 +1299,7 @@ static bool fused_tail_usable(const dr_handle* h) {
 
 static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s) {
     if (!h->finalized) DR_FAIL(h, DR_E_STATE, "forward before dr_finalize_params");
-    pipeline_drain(h);                                       // (training handle with two micro-step slots: the bound slot's buffers are reused)
+    if (pipeline_drain(h)) DR_FAIL(h, DR_E_DEVICE, "a micro-step slot's stream did not drain");   // (two micro-step slots: the bound slot's buffers are reused)
     if (B < 1 || B > h->cfg.max_batch) DR_FAIL(h, DR_E_INVALID, "batch %d outside [1, max_batch=%d]", B, h->cfg.max_batch);
     DR_ENTER(h);
     h->dm_in = dm;
@@ -1235,7 +1309,7 @@ static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s
         if (rc) return rc;
         h->fold_is_eval = true;
     }
-    const bool fuse = fused_tail_usable(h);
+    bool fuse = fused_tail_usable(h);
     size_t next_region = 0;                                  // regions are disjoint and in op order
     for (int i = 0; i < (int)h->ops.size(); ++i) {
         const Op& op = h->ops[i];
@@ -1244,10 +1318,15 @@ static int forward_eval_impl(dr_handle* h, int B, const float* dm, hipStream_t s
             if (i == fr.pool_op) {                           // the pool and everything in [first_op, last_op]: one launch, here
                 h->prof_tag = -1;
                 int rc = run_fused_region(h, fr, B, s);
-                if (rc) return rc;
-                continue;
+                if (rc == DR_OK) continue;
+                if (rc != DR_E_UNSUPPORTED) return rc;
+                // the device refused the kernel's LDS: this handle runs the region's ops one by one from here on (nothing of the
+                // region has been skipped yet: its pool is this op)
+                fprintf(stderr, "densereg: fused hourglass bottom unavailable on device %d, running the unfused ops\n", h->cfg.device);
+                h->fuse_tail = false;
+                fuse = false;
             }
-            if (i >= fr.first_op && i <= fr.last_op) {
+            if (fuse && i >= fr.first_op && i <= fr.last_op) {
                 if (i == fr.last_op) ++next_region;
                 continue;
             }
@@ -1382,7 +1461,7 @@ int dr_infer(dr_handle* h, int B, const float* dm, const float* cfg, const float
 
 int dr_read_activation(dr_handle* h, const char* scope, int B, float* host, size_t count) {
     if (!h || !scope || !host) return DR_E_INVALID;
-    pipeline_drain(h);
+    if (pipeline_drain(h)) DR_FAIL(h, DR_E_DEVICE, "a micro-step slot's stream did not drain");
     for (size_t oi = 0; oi < h->ops.size(); ++oi) {
         const Op& op = h->ops[oi];
         if ((op.kind != OP_CONV && op.kind != OP_STEM) || h->convs[op.conv].name != scope) continue;
@@ -1439,7 +1518,7 @@ extern "C" int dr_lookback_expired(dr_handle* h) {
 
 extern "C" int dr_profile_enable(dr_handle* h, int on) {
     if (!h) return DR_E_INVALID;
-    pipeline_drain(h);
+    if (pipeline_drain(h)) DR_FAIL(h, DR_E_DEVICE, "a micro-step slot's stream did not drain");
     rt::sync_stream(nullptr);
     for (auto& r : h->prof) { rt::event_destroy(r.a); rt::event_destroy(r.b); }
     h->prof.clear();

@@ -52,6 +52,9 @@ inline bool allow_dyn_lds(const void*, size_t) { return true; }
 // Product build: HIP for gfx950.
 // ---------------------------------------------------------------------------------------------
 #include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <thread>
 #define DR_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__)
 #define DR_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
@@ -65,7 +68,29 @@ inline int memset_async(void* p, int v, size_t n, hipStream_t s) { return hipMem
 inline int h2d(void* d, const void* h, size_t n, hipStream_t s) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1; }
 inline int d2h(void* h, const void* d, size_t n, hipStream_t s) { return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess ? 0 : -1; }
 inline int d2d(void* d, const void* s_, size_t n, hipStream_t s) { return hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1; }
-inline int sync_stream(hipStream_t s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+// Host-blocking wait, BOUNDED: a stream that does not drain within DR_SYNC_TIMEOUT_S seconds (default 120; 0 = wait forever) is
+// reported (-2, one line on stderr) instead of hanging the caller -- every wait of the library goes through here (parameter I/O,
+// mode switches, pipeline_drain, dr_destroy).  The poll is hipStreamQuery with a short sleep: these are rare paths.
+inline int sync_stream(hipStream_t s) {
+    static const double limit = [] { const char* e = getenv("DR_SYNC_TIMEOUT_S"); return e ? atof(e) : 120.0; }();
+    if (!(limit > 0.0) || hipPeekAtLastError() != hipSuccess) return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
+    hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned nap_us = 5;
+    while (e == hipErrorNotReady) {
+        std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
+        if (nap_us < 200) nap_us *= 2;
+        e = hipStreamQuery(s);
+        if (e == hipErrorNotReady && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            fprintf(stderr, "densereg: a stream did not drain within %.0f s (DR_SYNC_TIMEOUT_S): giving up the wait\n", limit);
+            if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();
+            return -2;
+        }
+    }
+    if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();     // (a poll's "not ready" is not an error of the caller's)
+    return e == hipSuccess ? 0 : -1;
+}
 inline int last_error(std::string* msg) {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) return 0;

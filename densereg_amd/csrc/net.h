@@ -116,6 +116,7 @@ enum KernelId {
     KID_CONV_128x128, KID_CONV_64x128, KID_CONV_128x64, KID_CONV_64x64, KID_CONV_128x32, KID_CONV_64x64_K64, KID_CONV_SPLITK, KID_CONV_64x96, KID_CONV_64x160, KID_CONV16_64x80, KID_CONV16_64x144, KID_CONV16_64x160, KID_STEM, KID_POOL, KID_UPADD, KID_UVD, KID_COPY,
     KID_HG_FUSED, KID_VOTE, KID_BN, KID_WGRAD, KID_WGRAD_FOLD, KID_ELTWISE, KID_LOSS, KID_ADAM,
     KID_WGRAD_128, KID_WGRAD_64, KID_WGRAD_ROW, KID_WGRAD_GROUP, KID_WGRAD_16,   // one row per weight-gradient kernel template (KID_WGRAD: the stem's)
+    KID_CONV_X3,                     // conv_x3.h (named conv_x3_128x128: bench.py prices it against the bf16 matrix cores / 6)
     KID_COUNT
 };
 static const char* const kKernelNames[KID_COUNT] = {
@@ -123,7 +124,7 @@ static const char* const kKernelNames[KID_COUNT] = {
     "conv_igemm_64x96", "conv_igemm_64x160", "conv_igemm16_64x80", "conv_igemm16_64x144", "conv_igemm16_64x160",
     "stem_conv", "maxpool",
     "upsample_add", "uvd", "copy_channels", "hourglass_tail_fused", "vote", "batch_renorm", "stem_wgrad", "wgrad_fold", "eltwise_bwd", "loss", "adam",
-    "conv_wgrad_128", "conv_wgrad_64", "conv_wgrad_row96", "conv_wgrad_group", "conv_wgrad16"};
+    "conv_wgrad_128", "conv_wgrad_64", "conv_wgrad_row96", "conv_wgrad_group", "conv_wgrad16", "conv_x3_128x128"};
 
 // The part of one hourglass below 16x16 pixels (hg_fused.h): in eval mode the ops [first_op, last_op] and the pool at pool_op are
 // ONE launch.  conv[]: the ConvLayer indices of its eight residual modules in execution order.
@@ -177,6 +178,7 @@ struct dr_handle {
     float* shadow = nullptr;     size_t n_shadow = 0;      // zero-debias biased accumulators
     float* wp = nullptr;         size_t n_wp = 0;          // packed forward weights
     float* wpT = nullptr;        size_t n_wpT = 0;         // packed dgrad weights
+    __bf16* wp3 = nullptr;       __bf16* wp3T = nullptr;   // conv_x3.h: the same two buffers as three bf16 planes (3 * n_wp / 3 * n_wpT elements)
     float* fold = nullptr;       size_t n_fold = 0;        // per-BN-layer scale|shift
     float* bnc = nullptr;        size_t n_bnc = 0;
     float* act_arena = nullptr;  size_t n_act = 0;

@@ -139,7 +139,10 @@ class DataParallelTrainer:
         supported = getattr(eng, 'groups_supported', None)
         if supported is not None and not supported(B // G, G):
             # what the one-pass window cannot take (micro-batches that are not a multiple of 8 crops, a window larger than the
-            # engine's max_batch, more than 8 micro-batches): the same window as G micro-steps -- same result, G passes of launches
+            # engine's max_batch, more than 8 micro-batches): the same window as G micro-steps, G passes of launches.  Same result
+            # with dropout off or with an injected keep mask; with DR_DROPOUT_RNG the two paths draw DIFFERENT (equally valid) keep
+            # bits -- one pass keys them by (rank_seed(seed), element of the 5x40-crop tensor), the loop by (seed*G+g, element of a
+            # 40-crop tensor) -- so a run that switches paths is not bit-comparable across the switch
             Bg, out = B // G, []
             for g in range(G):
                 sl = slice(g * Bg, (g + 1) * Bg)

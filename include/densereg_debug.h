@@ -94,6 +94,9 @@ int dr_dbg_force_bf16(int on);
  * dr_dbg_conv2d reads x as bf16 elements (x_cs = element stride), dr_dbg_wgrad reads g as bf16 elements, dr_dbg_bn_layer
  * writes draw as bf16 elements (the executor stores a BatchReNorm layer's dRaw that way on the bf16 path). */
 int dr_dbg_force_bf16_storage(int on);
+/* conv_x3.h (fp32-accurate products on the bf16 matrix cores): -1 = DR_CONV_X3 / the measured rule, 0 = never, 1 = the rule, 2 = wherever
+ * the kernel can run -- for the debug entries and every handle of the process */
+int dr_dbg_force_x3(int mode);
 
 /* Partial statistics rows one wave of a BatchReNorm finalize launch folds before the micro-batch group gets another wave
  * (densereg_amd/csrc/train_kernels.h: bn_finalize_split; default 512, 0 restores it).  Process-global; tests lower it so that

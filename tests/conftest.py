@@ -52,6 +52,9 @@ def pytest_collection_modifyitems(config, items):
     def key(it):
         return (rank.get(os.path.basename(str(it.fspath)), len(_FILE_ORDER) - 1), pos[id(it)])
     items.sort(key=key)
+    for it in items:                      # a GPU test that stalls is cut (and named, with every thread's stack) long before the suite's wall-clock limit
+        if it.get_closest_marker('gpu') is not None and it.get_closest_marker('timeout') is None:
+            it.add_marker(pytest.mark.timeout(240))
 
 
 # ---- one flushed line per test: the tail of a log that was cut names the last finished test and the running one -------------------

@@ -84,6 +84,42 @@ def test_conv_splitk_kernel_fused_epilogue(be, case, tile):
     np.testing.assert_allclose(st[1], (raw ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-4)
 
 
+X3_CASES = CONV_CASES + [
+    # (B, H, W, Cin, Cout, k): more than one 128-row / 128-column block, ragged rows, K tails of 1..3 channels, Cout beyond a block
+    (2, 12, 11, 64, 128, 3), (1, 16, 16, 256, 256, 1), (3, 7, 7, 33, 130, 3), (1, 20, 13, 515, 200, 1), (2, 8, 8, 18, 40, 3),
+]
+
+
+@pytest.mark.parametrize('case', X3_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_x3_fp32_accurate_products_on_the_bf16_matrix_cores(be, case):
+    """conv_x3.h: every operand split into three bf16 terms, six cross products per fp32 product on v_mfma_f32_32x32x16_bf16 -- the
+    SAME 2e-5 bar against the fp64 definition as the fp32-MFMA kernels, every fused epilogue feature, and an error no larger than
+    a small multiple of the fp32 kernel's own on the same problem (so the layer's numbers are fp32 numbers whichever kernel ran)."""
+    B, H, W, Cin, Cout, k = case
+    rng = np.random.default_rng(hash(case) % 2**31 + 9)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    x *= np.exp(rng.uniform(-6, 6, x.shape)).astype(np.float32)             # operands across twelve binades: every split term matters
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
+    mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if k == 1 else None
+    yr, raw = ref_conv2d(x, w, scale, shift, True, res, mask, -0.5)
+    outs = {}
+    for mode in (0, 2):
+        try:
+            assert be.dbg.dr_dbg_force_x3(mode) == 0
+            outs[mode] = be.conv2d(x, w, scale, shift, True, res, mask, -0.5, want_stats=True)
+        finally:
+            be.dbg.dr_dbg_force_x3(-1)
+    e32, e3 = _rel(outs[0][0], yr), _rel(outs[2][0], yr)
+    assert e3 < 2e-5, (e3, e32)
+    assert e3 < 4 * e32 + 1e-7, (e3, e32)
+    for y, st in outs.values():
+        np.testing.assert_allclose(st[0], raw.sum((0, 1, 2)), rtol=1e-4, atol=1e-4 * float(np.abs(raw).max()) * raw[..., 0].size ** 0.5)
+        np.testing.assert_allclose(st[1], (raw ** 2).sum((0, 1, 2)), rtol=1e-4)
+
+
 MF16_CASES = [            # (B, H, W, Cin, Cout, k): output widths of the 16-column tiles, ragged and full, odd images, short / long K
     (1, 9, 7, 156, 78, 1), (2, 5, 6, 78, 78, 3), (1, 8, 8, 131, 65, 1), (1, 7, 9, 65, 65, 3), (2, 6, 6, 64, 80, 1),
     (1, 5, 5, 170, 131, 1), (1, 6, 7, 33, 142, 3), (2, 4, 9, 259, 129, 1), (1, 8, 5, 78, 156, 1), (1, 3, 3, 19, 160, 3), (3, 11, 3, 4, 145, 1),

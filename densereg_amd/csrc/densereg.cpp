@@ -171,7 +171,9 @@ bool conv_use_x3(const ConvParams& p) {
     const long M = (long)p.B * p.H * p.W;
     const int ncols = p.Ng > 0 ? p.Ng : p.Np;
     // whole 128-column blocks (a 160-column layer would compute 256), and a grid of at least two workgroups per CU
-    return ncols % 128 == 0 && dr_ceil_div((int)M, 128) * (long)(ncols / 128) >= 512 && (long)p.ksize * p.ksize * p.Kp >= 128;
+    if (ncols % 128 == 0) return dr_ceil_div((int)M, 128) * (long)(ncols / 128) >= 512 && (long)p.ksize * p.ksize * p.Kp >= 128;
+    static const bool bn64 = [] { const char* e = getenv("DR_X3_BN64"); return e && e[0] == '1'; }();
+    return bn64 && ncols % 64 == 0 && dr_ceil_div((int)M, 128) * (long)(ncols / 64) >= 1024 && (long)p.ksize * p.ksize * p.Kp >= 128;
 }
 
 // output rows per workgroup of the tile a problem gets
@@ -192,13 +194,21 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     if (p.bst_raw_bf16 && (!p.bst_raw || p.bst_act || p.scale || p.shift || p.relu || p.drop || p.drop_rng)) return -1;
     if (conv_tile_id(p) == KID_CONV_X3) {
         static const int nfast = [] { const char* e = getenv("DR_CONV_NFAST"); return (e && e[0] == '0') ? 0 : 1; }();
+        static const int variant = [] { const char* e = getenv("DR_X3_VARIANT"); return e ? atoi(e) : 0; }();
         ConvParams q = p;
         q.nfast = nfast;
-        dim3 grid(dr_ceil_div((int)M, 128), dr_ceil_div(p.Ng > 0 ? p.Ng : p.Np, 128));
+        const int ncols = p.Ng > 0 ? p.Ng : p.Np;
+        const bool bn64 = ncols % 128 != 0 && ncols % 64 == 0;               // 64-column blocks where 128 would compute padding
+        dim3 grid(dr_ceil_div((int)M, 128), dr_ceil_div(ncols, bn64 ? 64 : 128));
         q.gx = (int)grid.x; q.gy = (int)grid.y;
-        static const int variant = [] { const char* e = getenv("DR_X3_VARIANT"); return e ? atoi(e) : 0; }();
-        if (variant == 1 || g_dbg_x3 == 3) DR_LAUNCH((conv_x3_kernel<128, 128, 0>), grid, dim3(256), 0, s, q);
-        else DR_LAUNCH((conv_x3_kernel<128, 128, 1>), grid, dim3(256), 0, s, q);
+        const bool one_acc = variant == 1 || g_dbg_x3 == 3;
+        if (bn64) {
+            if (one_acc) DR_LAUNCH((conv_x3_kernel<128, 64, 0>), grid, dim3(256), 0, s, q);
+            else DR_LAUNCH((conv_x3_kernel<128, 64, 1>), grid, dim3(256), 0, s, q);
+        } else {
+            if (one_acc) DR_LAUNCH((conv_x3_kernel<128, 128, 0>), grid, dim3(256), 0, s, q);
+            else DR_LAUNCH((conv_x3_kernel<128, 128, 1>), grid, dim3(256), 0, s, q);
+        }
         return 0;
     }
     if (conv_tile_id(p) == KID_CONV_SPLITK) {

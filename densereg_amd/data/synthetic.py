@@ -76,3 +76,63 @@ def make_crops(batch: int, dataset: str = 'icvl', seed: int = 20240, rank: int =
         dms[b, :, :, 0], poses[b], cfgs[b], coms[b] = dm, pose.reshape(-1), cfg, com
     names = ['synthetic_%s/rank%d_%07d.png' % (dataset, rank, i) for i in range(batch)]
     return dms, poses, cfgs, coms, names
+
+
+def make_hand_crops(batch: int, dataset: str = 'icvl', seed: int = 7, rank: int = 0, hw: int = 128):
+    """LEARNABLE synthetic crops: an articulated "hand" whose joints are a function of what the camera sees -- joint 0 the palm
+    centre, the others at equal fractions along five fingers in a fixed cyclic order (finger f = (j-1) % 5), every joint 6 mm
+    behind the visible surface.  ``make_crops`` (the throughput workload) picks its joints at random among the foreground pixels:
+    nothing there to learn.  Same return convention; used by the training tests and ``examples/train_synthetic.py``, where the
+    engine's own training has to make the heat-maps peaked (hourglass_um_crop_tiny.py:193-274 targets, :323-371 loss)."""
+    ds = DATASETS[dataset]
+    J = ds['jnt_num']
+    rng = np.random.Generator(np.random.PCG64(1_000_003 * seed + rank))
+    dms = np.zeros((batch, hw, hw, 1), np.float32)
+    poses = np.zeros((batch, 3 * J), np.float32)
+    cfgs = np.zeros((batch, 6), np.float32)
+    coms = np.zeros((batch, 3), np.float32)
+    vv, uu = np.meshgrid(np.arange(hw, dtype=np.float32), np.arange(hw, dtype=np.float32), indexing='ij')
+    sc = hw / 128.0
+    nseg = -(-(J - 1) // 5)                                   # joints per finger (the last fingers may have one fewer)
+    for b in range(batch):
+        com_z = rng.uniform(300.0, 800.0)
+        L = rng.uniform(100.0, 140.0)
+        cu, cv = hw / 2.0 + rng.normal(0, 4.0 * sc), hw / 2.0 + rng.normal(0, 4.0 * sc)      # where the palm sits in the crop
+        cfg = np.array([ds['fx'] * hw / L, ds['fy'] * hw / L, hw / 2.0 + rng.normal(0, 2), hw / 2.0 + rng.normal(0, 2), hw, hw], np.float32)
+        rot = rng.normal(0, 0.12)
+        palm_r = rng.uniform(20.0, 24.0) * sc
+        tiltu, tiltv = rng.normal(0, 0.35, 2)                 # the palm plane's slope (mm of depth per pixel)
+        depth = com_z + tiltu * (uu - cu) + tiltv * (vv - cv) - 12.0 * np.exp(-((uu - cu) ** 2 + (vv - cv) ** 2) / (2 * (palm_r * 0.8) ** 2))
+        fg = np.hypot(uu - cu, vv - cv) < palm_r
+        tips = []
+        for f in range(5):
+            ang = rot - 0.5 * np.pi + (f - 2) * 0.52 + rng.normal(0, 0.07)       # a fan of five fingers, 30 degrees apart, pointing up
+            du, dv = np.cos(ang), np.sin(ang)
+            length = rng.uniform(44.0, 56.0) * sc * (0.8 if f in (0, 4) else 1.0)
+            curl = rng.normal(0, 0.5)                         # depth slope along the finger (mm per pixel): towards / away from the camera
+            t = np.clip((uu - cu) * du + (vv - cv) * dv, 0, length)
+            dist = np.hypot(uu - cu - t * du, vv - cv - t * dv)
+            finger = (dist < 4.5 * sc) & ~fg
+            zf = com_z + tiltu * (t * du) + tiltv * (t * dv) + curl * np.maximum(t - palm_r, 0.0) - 3.0 * np.cos(np.clip(dist / (4.5 * sc), 0, 1) * np.pi / 2)
+            depth = np.where(finger, zf, depth)
+            fg |= finger
+            tips.append((du, dv, length, curl))
+        depth = depth + rng.normal(0, 1.0, (hw, hw))
+        dm = np.where(fg, np.clip(depth, com_z - 140.0, com_z + 140.0), 0.0).astype(np.float32)
+        com = center_of_mass(dm, cfg)
+        pose = np.zeros((J, 3), np.float32)
+
+        def lift(u, v):
+            iu, iv = int(np.clip(round(u), 0, hw - 1)), int(np.clip(round(v), 0, hw - 1))
+            d = dm[iv, iu] if dm[iv, iu] > 0 else com_z
+            d = d + 6.0                                       # inside the hand, behind the surface the camera sees
+            return [(u - cfg[2]) * d / cfg[0], (v - cfg[3]) * d / cfg[1], d]          # data/util.py:21
+        pose[0] = lift(cu, cv)
+        for j in range(1, J):
+            f, sgm = (j - 1) % 5, (j - 1) // 5
+            du, dv, length, _ = tips[f]
+            t = palm_r + (length - palm_r - 2.0 * sc) * (sgm + 1) / nseg
+            pose[j] = lift(cu + t * du, cv + t * dv)
+        dms[b, :, :, 0], poses[b], cfgs[b], coms[b] = dm, pose.reshape(-1), cfg, com
+    names = ['synthetic_hand_%s/rank%d_%07d.png' % (dataset, rank, i) for i in range(batch)]
+    return dms, poses, cfgs, coms, names

@@ -8,6 +8,7 @@ import os
 import sys
 
 import numpy as np
+import torch  # noqa: F401  (before the library: torch brings its own HIP runtime, which must be the first one loaded)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from densereg_amd import _lib  # noqa: E402
@@ -35,7 +36,6 @@ def main():
             hw, hw, cin, cout, k, row[0], fl / row[0] / 1e6, row[1], fl / row[1] / 1e6, row[2], fl / row[2] / 1e6, row[0] / row[1]))
         sys.stdout.flush()
     # errors against fp64 on one big layer (network-like operands: post-ReLU activations, He weights)
-    import torch
     from tests.common import GpuBackend, ref_conv2d
     be = GpuBackend()
     rng = np.random.default_rng(3)

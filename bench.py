@@ -350,17 +350,28 @@ def main():
         if convs:
             dom = max(convs, key=lambda s: s['total_ms'])
             ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+            # conv_x3.h forms every fp32 product from SIX bf16 products on v_mfma_f32_32x32x16_bf16: its ceiling is the dense bf16
+            # matrix-core rate / 6 (416.7 TFLOP/s of algorithmic fp32-accurate FLOPs), not the fp32-MFMA rate it replaces
+            def peak_of(name):
+                return (PEAK_BF16_MFMA_TFLOPS / 6.0, 'bf16 MFMA dense %.0f TFLOP/s / 6 products per fp32-accurate product (conv_x3.h)' % PEAK_BF16_MFMA_TFLOPS) \
+                    if name.startswith('conv_x3') else (peak, ('bf16' if bf16 else 'fp32') + ' MFMA dense')
+            peak_dom, peak_basis = peak_of(dom['name'])
             pmc_mode = mode + ('_bf16' if bf16 else '') + ('' if (S, F, HW) == (2, 128, 128) else '_s%df%dhw%d' % (S, F, HW))
             traffic, traffic_prov = pmc_traffic(pmc_mode, dom['name'])
-            roof = {'kernel': dom['name'], 'bound': 'mfma', 'achieved': ach, 'peak': peak,
-                    'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic, 'traffic_provenance': traffic_prov,
+            roof = {'kernel': dom['name'], 'bound': 'mfma', 'achieved': ach, 'peak': peak_dom, 'peak_basis': peak_basis,
+                    'unit': 'TFLOP/s', 'frac': ach / peak_dom, 'traffic': traffic, 'traffic_provenance': traffic_prov,
+                    # GPU-busy evidence that does not depend on an external sampler: HIP-event time of every kernel of a profiled pass
+                    # (one stream, nothing overlaps) next to the wall time of a timed step
+                    'kernel_ms_per_profiled_pass': sum(s['total_ms'] for s in stats) / nprof,
+                    'timed_ms_per_pass': dt / args.steps * 1e3 * (G if mode == 'train' else 1),
                     'launches_per_step': dom['launches'] / nprof, 'avg_launch_us': dom['total_ms'] * 1e3 / dom['launches'],
                     'micro_steps_per_profiled_step': G, 'batches_per_profiled_step': MG,
                     'algorithmic_gflop_per_launch': dom['flops'] / dom['launches'] / 1e9,
                     'share_of_step_time': dom['total_ms'] / max(sum(s['total_ms'] for s in stats), 1e-9),
                     # the runner-up family, same accounting (training: the forward/dgrad tile and the weight gradients trade places)
                     'runner_up': (lambda r: {'kernel': r['name'], 'achieved': r['flops'] / (r['total_ms'] * 1e-3) / 1e12,
-                                             'frac': r['flops'] / (r['total_ms'] * 1e-3) / 1e12 / peak, 'launches_per_step': r['launches'] / nprof,
+                                             'frac': r['flops'] / (r['total_ms'] * 1e-3) / 1e12 / peak_of(r['name'])[0], 'peak': peak_of(r['name'])[0],
+                                             'launches_per_step': r['launches'] / nprof,
                                              'avg_launch_us': r['total_ms'] * 1e3 / r['launches']})(
                         sorted(convs, key=lambda s: -s['total_ms'])[1]) if len(convs) > 1 else None,
                     'all_kernels': {s['name']: {'ms_per_step': s['total_ms'] / nprof, 'launches': s['launches'] // nprof,

@@ -248,3 +248,18 @@ def flat_grads_by_name(be, h, cfg):
             off += cnt
     assert off == n
     return out
+
+
+def grad_metrics(g, ref):
+    """Per-tensor agreement of two gradient sets {name: array}: max-norm error (of the tensor's largest element), relative L2 error
+    and cosine -- the max-norm sees a single ReLU / max-pool switch, the L2 and cosine see a systematic few-per-cent error of a whole
+    tensor that the max-norm bar would let through.  Returns (names, max_err, rel_l2, cosine) as arrays (fp64 accumulation)."""
+    names = [n for n in ref if n in g]
+    mx, l2, cs = [], [], []
+    for n in names:
+        a, b = np.asarray(g[n], np.float64).ravel(), np.asarray(ref[n], np.float64).ravel()
+        nb = np.linalg.norm(b)
+        mx.append(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+        l2.append(np.linalg.norm(a - b) / (nb + 1e-300))
+        cs.append(float(a @ b) / (np.linalg.norm(a) * nb + 1e-300))
+    return names, np.array(mx), np.array(l2), np.array(cs)

@@ -155,6 +155,13 @@ def test_window_g5_b40_against_the_oracles_chained_micro_steps(gpu, dataset, J):
     print('window gradient vs the oracle (%s J=%d, fp32 autograd, %d micro-steps of %d crops summed): max %.2e median %.2e'
           % (dataset, J, G, BG, e.max(), np.median(e)))
     assert e.max() < 1.6e-1 and np.median(e) < 2e-2, (e.max(), np.median(e))       # the bar of tests/test_train_parity.py (1)
+    from tests.common import grad_metrics
+    from tests.test_train_parity import GRAD_COS_MIN, GRAD_L2_MEDIAN, GRAD_L2_WORST
+    names, _, l2, cs = grad_metrics(grads, gsum)
+    w = int(np.argmax(l2))
+    print('window gradient vs the oracle, per tensor: rel-L2 max %.2e (%s) median %.2e | cosine min %.6f median %.8f'
+          % (l2.max(), names[w], np.median(l2), cs.min(), np.median(cs)))
+    assert l2.max() < GRAD_L2_WORST and np.median(l2) < GRAD_L2_MEDIAN and cs.min() > GRAD_COS_MIN, (l2.max(), names[w], np.median(l2), cs.min())
 
 
 def test_config4_msra_j21_train_b40(gpu):

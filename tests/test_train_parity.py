@@ -14,7 +14,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.common import _flat_rw, flat_grads_by_name
+from tests.common import _flat_rw, flat_grads_by_name, grad_metrics
 
 BACKENDS = [pytest.param('emu'), pytest.param('gpu', marks=pytest.mark.gpu)]
 
@@ -22,6 +22,11 @@ BACKENDS = [pytest.param('emu'), pytest.param('gpu', marks=pytest.mark.gpu)]
 @pytest.fixture(params=BACKENDS)
 def be(request):
     return request.getfixturevalue(request.param)
+
+
+# per-tensor relative-L2 / cosine bars of the fp32 gradient against the oracle's fp32 autograd (set from the MI355X measurement printed
+# by _run_step; the max-norm bars stay what they were)
+GRAD_L2_WORST, GRAD_L2_MEDIAN, GRAD_COS_MIN = 5e-2, 5e-3, 0.998
 
 
 def _case(S, F, J, B, dataset='icvl'):
@@ -88,6 +93,15 @@ def _run_step(be, cfg, params, ndm, poses, cfgs, coms, masks, ref64=True):
     # F=256 network -- torch-fp32 itself is 0.46 from fp64 on its worst tensor -- is always small enough for (2))
     if cfg.num_stack <= 2 and cfg.in_hw == 128:
         assert e_pair.max() < 1.6e-1 and np.median(e_pair) < 2e-2, (e_pair.max(), np.median(e_pair))
+    # (1b) the statement a max-norm cannot make: per tensor, relative L2 error and cosine against the oracle's gradient -- a
+    # systematic few-per-cent error of one tensor (a wrong scale, a missing term) moves these, a single ReLU switch does not
+    names, _, l2_pair, cos_pair = grad_metrics(g, g32)
+    w = int(np.argmax(l2_pair))
+    print('grad vs the fp32 oracle, per tensor: rel-L2 max %.2e (%s) median %.2e | cosine min %.6f median %.8f'
+          % (l2_pair.max(), names[w], np.median(l2_pair), cos_pair.min(), np.median(cos_pair)))
+    if be.name == 'gpu' or cfg.num_stack <= 2:
+        assert l2_pair.max() < GRAD_L2_WORST and np.median(l2_pair) < GRAD_L2_MEDIAN and cos_pair.min() > GRAD_COS_MIN, \
+            (l2_pair.max(), names[w], np.median(l2_pair), cos_pair.min())
     _record_branch('ref64' if ref64 else 'fp32-only', B, cfg)
     g64 = g32
     if ref64:
@@ -108,6 +122,13 @@ def _run_step(be, cfg, params, ndm, poses, cfgs, coms, masks, ref64=True):
         assert e_eng.max() < max(6e-2, 1.25 * e_o32.max()), (e_eng.max(), e_o32.max())
         assert np.median(e_eng) < max(1e-2, 1.25 * np.median(e_o32))
         assert np.median(e_eng) < 2 * np.median(e_o32) + 1e-4
+        _, _, l2_e, cos_e = grad_metrics(g, g64)
+        _, _, l2_o, cos_o = grad_metrics(g32, g64)
+        print('grad vs the fp64 oracle, per tensor rel-L2: engine max %.2e median %.2e | torch-fp32 max %.2e median %.2e ; cosine min: engine %.6f torch-fp32 %.6f'
+              % (l2_e.max(), np.median(l2_e), l2_o.max(), np.median(l2_o), cos_e.min(), cos_o.min()))
+        # the engine's fp32 gradient is as close to the fp64 gradient as torch's fp32 autograd of the same graph is
+        assert l2_e.max() < max(2 * l2_o.max(), 1e-3) and np.median(l2_e) < max(2 * np.median(l2_o), 1e-4), (l2_e.max(), l2_o.max())
+        assert 1 - cos_e.min() < max(4 * (1 - cos_o.min()), 1e-6), (cos_e.min(), cos_o.min())
     # a second loss+backward on the same forward must add exactly the same gradient again: catches gradient
     # buffers that are neither zeroed nor overwritten by their first writer (train_exec.inc plan_backward)
     h.call('dr_loss', B, be.ptr(d_dm), be.ptr(d_pose), be.ptr(d_cfg), be.ptr(d_com), be.ptr(d_lo), be.stream)

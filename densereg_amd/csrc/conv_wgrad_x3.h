@@ -105,9 +105,9 @@ __global__ __launch_bounds__(256, (T == 128 ? 2 : 4)) void conv_wgrad_x3_kernel(
         uint2 l0, l1, l2, u0, u1, u2;
         x3_split4(lo4, l0, l1, l2);
         x3_split4(hi4, u0, u1, u2);
-        h0 = __builtin_bit_cast(float4, make_uint4(l0.x, l0.y, u0.x, u0.y));
-        h1 = __builtin_bit_cast(float4, make_uint4(l1.x, l1.y, u1.x, u1.y));
-        h2 = __builtin_bit_cast(float4, make_uint4(l2.x, l2.y, u2.x, u2.y));
+        h0 = make_float4(__builtin_bit_cast(float, l0.x), __builtin_bit_cast(float, l0.y), __builtin_bit_cast(float, u0.x), __builtin_bit_cast(float, u0.y));
+        h1 = make_float4(__builtin_bit_cast(float, l1.x), __builtin_bit_cast(float, l1.y), __builtin_bit_cast(float, u1.x), __builtin_bit_cast(float, u1.y));
+        h2 = make_float4(__builtin_bit_cast(float, l2.x), __builtin_bit_cast(float, l2.y), __builtin_bit_cast(float, u2.x), __builtin_bit_cast(float, u2.y));
     };
     auto store = [&](const int buf) __attribute__((always_inline)) {
         if (CHUNKS < 256 && !stager) return;
@@ -153,8 +153,10 @@ __global__ __launch_bounds__(256, (T == 128 ? 2 : 4)) void conv_wgrad_x3_kernel(
                 const uint2 a1 = dr_lds_read_tr16(&DR_XS(buf)[pl][t_pix + 4][wm * WT + 32 * t + t_ch]);
                 const uint2 b0 = dr_lds_read_tr16(&DR_GS(buf)[pl][t_pix][wn * WT + 32 * t + t_ch]);
                 const uint2 b1 = dr_lds_read_tr16(&DR_GS(buf)[pl][t_pix + 4][wn * WT + 32 * t + t_ch]);
-                a[pl][t] = __builtin_bit_cast(dr_bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
-                b[pl][t] = __builtin_bit_cast(dr_bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
+                a[pl][t] = __builtin_bit_cast(dr_bf16x8, make_float4(__builtin_bit_cast(float, a0.x), __builtin_bit_cast(float, a0.y),
+                                                                       __builtin_bit_cast(float, a1.x), __builtin_bit_cast(float, a1.y)));
+                b[pl][t] = __builtin_bit_cast(dr_bf16x8, make_float4(__builtin_bit_cast(float, b0.x), __builtin_bit_cast(float, b0.y),
+                                                                       __builtin_bit_cast(float, b1.x), __builtin_bit_cast(float, b1.y)));
             }
         auto mf = [&](auto NA, auto NB) __attribute__((always_inline)) {
 #define X3W_MMA(c, pa, pb)                                                                                                     \

@@ -12,6 +12,7 @@
 #include "conv_wgrad.h"
 #include "conv_wgrad_bf16.h"
 #include "conv_wgrad_tr.h"
+#include "conv_wgrad_x3.h"
 #include "frontend.h"
 #include "dataio.h"
 #include "kernels_misc.h"

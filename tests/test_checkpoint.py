@@ -175,3 +175,140 @@ def test_engine_export_restore_round_trip(emu, tmp_path):
         ck.load_into(emu.handle(cfg, 1, training=True), prefix)
     assert 'Conv/weights' in ck.load_into(emu.handle(cfg, 1, training=True), prefix, strict=False)['missing']
     h.close(); h2.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Independent implementations (nothing below is encoded by densereg_amd/checkpoint.py): Google's snappy library through pyarrow, and
+# the official protobuf runtime on message types declared from TensorFlow's public tensor_bundle.proto / tensor_shape.proto /
+# versions.proto / tensor_slice.proto field numbers.  What stays unpinned by any independent writer is the leveldb table container
+# itself (footer, block handles, restart arrays): no leveldb and no TensorFlow exists in this image -- INTEGRATION.md says so.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _snappy_cases():
+    rng = np.random.default_rng(5)
+    yield b''
+    yield b'a'
+    yield bytes(rng.integers(0, 256, 61, dtype=np.uint8))                       # a literal one byte past the 60-byte inline length
+    yield bytes(rng.integers(0, 256, 70000, dtype=np.uint8))                    # incompressible: long literals (2- and 3-byte lengths)
+    yield b'abcabcabcabc' * 50 + b'xyz'                                         # overlapping copies (offset < length)
+    yield (b'0123456789abcdef' * 8 + bytes(rng.integers(0, 256, 3000, dtype=np.uint8))) * 40     # copies with 2-byte offsets
+    blob = bytes(rng.integers(0, 4, 200000, dtype=np.uint8))                    # low-entropy: many short copies at every distance
+    yield blob
+    yield blob[:66000] + bytes(rng.integers(0, 256, 70000, dtype=np.uint8)) + blob[:66000]      # a match further than 64 KB back
+
+
+def test_snappy_decoder_against_googles_encoder():
+    """``snappy_decompress`` on raw snappy blocks produced by Google's library (pyarrow's codec): every element type the format has
+    -- inline and extended literal lengths, copies with 1- and 2-byte offsets (4-byte ones where the encoder emits them), overlapping
+    copies -- decoded back to the input, and the official decoder agreeing on the same bytes."""
+    pa = pytest.importorskip('pyarrow')
+    if not pa.Codec.is_available('snappy'):
+        pytest.skip('pyarrow without snappy')
+    kinds = set()
+    for data in _snappy_cases():
+        comp = pa.compress(data, codec='snappy', asbytes=True)
+        assert ck.snappy_decompress(comp) == data
+        assert pa.decompress(comp, decompressed_size=len(data), codec='snappy', asbytes=True) == data
+        pos = ck.get_varint(comp, 0)[1]
+        while pos < len(comp):                                                  # walk the elements: which tag kinds did the encoder use?
+            tag = comp[pos]; kind = tag & 3; kinds.add(kind)
+            if kind == 0:
+                ln = tag >> 2
+                nb = ln - 59 if ln >= 60 else 0
+                ln = int.from_bytes(comp[pos + 1:pos + 1 + nb], 'little') if nb else ln
+                pos += 1 + nb + ln + 1
+            else:
+                pos += {1: 2, 2: 3, 3: 5}[kind]
+    assert {0, 1, 2} <= kinds, kinds
+
+
+def test_snappy_compressed_table_blocks_written_by_googles_encoder(tmp_path):
+    """A table whose data blocks are snappy-compressed by Google's encoder (type byte 1, masked CRC-32C over compressed bytes + type,
+    as table/format.cc lays a block out) read back by ``read_table``: the compressed-block path TF's own writer does not take but
+    other bundle writers may."""
+    pa = pytest.importorskip('pyarrow')
+    if not pa.Codec.is_available('snappy'):
+        pytest.skip('pyarrow without snappy')
+    items = [(('var_%04d/weights' % i).encode(), bytes([i % 251]) * (40 + i % 7)) for i in range(300)]
+    blocks, index_items, out = [], [], bytearray()
+
+    def emit(raw_block, compress):
+        body = pa.compress(raw_block, codec='snappy', asbytes=True) if compress else raw_block
+        typ = b'\x01' if compress else b'\x00'
+        off = len(out)
+        out.extend(body + typ + struct.pack('<I', ck.mask_crc(ck.crc32c(body + typ))))
+        return off, len(body)
+    for i in range(0, len(items), 50):
+        chunk = items[i:i + 50]
+        off, size = emit(ck._build_block(chunk), compress=True)
+        index_items.append((chunk[-1][0], ck.put_varint(off) + ck.put_varint(size)))
+    moff, msize = emit(ck._build_block([]), compress=False)
+    ioff, isize = emit(ck._build_block(index_items, restart_interval=1), compress=True)
+    footer = ck.put_varint(moff) + ck.put_varint(msize) + ck.put_varint(ioff) + ck.put_varint(isize)
+    out.extend(footer + b'\x00' * (40 - len(footer)) + bytes.fromhex('57fb808b247547db'))      # table/format.h: kTableMagicNumber, little endian
+    path = tmp_path / 'snappy.index'
+    path.write_bytes(bytes(out))
+    assert ck.read_table(str(path)) == items
+
+
+def _bundle_protos():
+    """BundleHeaderProto / BundleEntryProto (+ TensorShapeProto, TensorSliceProto, VersionDef) declared from the field numbers of
+    TensorFlow's public .proto files, instantiated by the OFFICIAL protobuf runtime."""
+    pytest.importorskip('google.protobuf')
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(name='dr_tensor_bundle_test.proto', package='drtest', syntax='proto3')
+
+    def msg(name, fields, nested=()):
+        m = descriptor_pb2.DescriptorProto(name=name)
+        for fname, num, typ, label, tname in fields:
+            f = m.field.add(name=fname, number=num, type=typ, label=label)
+            if tname:
+                f.type_name = tname
+        for n in nested:
+            m.nested_type.add().CopyFrom(n)
+        return m
+    OPT, REP = F.LABEL_OPTIONAL, F.LABEL_REPEATED
+    dim = msg('Dim', [('size', 1, F.TYPE_INT64, OPT, ''), ('name', 2, F.TYPE_STRING, OPT, '')])
+    fd.message_type.add().CopyFrom(msg('TensorShapeProto', [('dim', 2, F.TYPE_MESSAGE, REP, '.drtest.TensorShapeProto.Dim'),
+                                                            ('unknown_rank', 3, F.TYPE_BOOL, OPT, '')], nested=[dim]))
+    ext = msg('Extent', [('start', 1, F.TYPE_INT64, OPT, ''), ('length', 2, F.TYPE_INT64, OPT, '')])
+    fd.message_type.add().CopyFrom(msg('TensorSliceProto', [('extent', 1, F.TYPE_MESSAGE, REP, '.drtest.TensorSliceProto.Extent')], nested=[ext]))
+    fd.message_type.add().CopyFrom(msg('VersionDef', [('producer', 1, F.TYPE_INT32, OPT, ''), ('min_consumer', 2, F.TYPE_INT32, OPT, ''),
+                                                      ('bad_consumers', 3, F.TYPE_INT32, REP, '')]))
+    fd.message_type.add().CopyFrom(msg('BundleHeaderProto', [('num_shards', 1, F.TYPE_INT32, OPT, ''), ('endianness', 2, F.TYPE_INT32, OPT, ''),
+                                                             ('version', 3, F.TYPE_MESSAGE, OPT, '.drtest.VersionDef')]))
+    fd.message_type.add().CopyFrom(msg('BundleEntryProto', [
+        ('dtype', 1, F.TYPE_INT32, OPT, ''), ('shape', 2, F.TYPE_MESSAGE, OPT, '.drtest.TensorShapeProto'), ('shard_id', 3, F.TYPE_INT32, OPT, ''),
+        ('offset', 4, F.TYPE_INT64, OPT, ''), ('size', 5, F.TYPE_INT64, OPT, ''), ('crc32c', 6, F.TYPE_FIXED32, OPT, ''),
+        ('slices', 7, F.TYPE_MESSAGE, REP, '.drtest.TensorSliceProto')]))
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    get = getattr(message_factory, 'GetMessageClass', None)
+    cls = (lambda n: get(pool.FindMessageTypeByName('drtest.' + n))) if get else \
+          (lambda n: message_factory.MessageFactory(pool).GetPrototype(pool.FindMessageTypeByName('drtest.' + n)))
+    return cls('BundleHeaderProto'), cls('BundleEntryProto')
+
+
+def test_bundle_protos_against_the_official_protobuf_runtime():
+    """``parse_entry`` on entries SERIALIZED by the protobuf runtime (any field order it chooses, zero / large / negative values, a
+    sliced entry), and ``build_entry`` / ``build_header`` PARSED by it: the wire-format code of the importer and exporter against an
+    encoder and a decoder it does not share a line with."""
+    Header, Entry = _bundle_protos()
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        shape = [int(v) for v in rng.integers(1, 600, int(rng.integers(0, 5)))]
+        e = Entry(dtype=int(rng.choice([1, 3, 9])), shard_id=int(rng.integers(0, 3)), offset=int(rng.integers(0, 1 << 40)),
+                  size=int(rng.integers(0, 1 << 33)), crc32c=int(rng.integers(0, 1 << 32)))
+        for d in shape:
+            e.shape.dim.add(size=d)
+        if trial % 7 == 0:
+            e.slices.add().extent.add(start=0, length=4)
+        got = ck.parse_entry(e.SerializeToString())
+        assert (got['dtype'], got['shape'], got['shard_id'], got['offset'], got['size'], got['crc32c'], got['sliced']) == \
+               (e.dtype, shape, e.shard_id, e.offset, e.size, e.crc32c, trial % 7 == 0)
+        # the exporter's bytes, read by the official decoder
+        back = Entry.FromString(ck.build_entry(e.dtype, shape, e.offset, e.size, e.crc32c))
+        assert (back.dtype, [d.size for d in back.shape.dim], back.offset, back.size, back.crc32c, back.shard_id) == \
+               (e.dtype, shape, e.offset, e.size, e.crc32c, 0)
+    h = Header.FromString(ck.build_header(num_shards=1, producer=1))
+    assert (h.num_shards, h.endianness, h.version.producer) == (1, 0, 1)

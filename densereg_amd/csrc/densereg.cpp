@@ -172,11 +172,12 @@ bool conv_use_x3(const ConvParams& p) {
     const long M = (long)p.B * p.H * p.W;
     const int ncols = p.Ng > 0 ? p.Ng : p.Np;
     // whole 128-column blocks (a 160-column layer would compute 256), and a grid of at least two workgroups per CU
-    if (ncols % 128 == 0) return dr_ceil_div((int)M, 128) * (long)(ncols / 128) >= 512 && (long)p.ksize * p.ksize * p.Kp >= 128;
+    static const long min_wgs = [] { const char* e = getenv("DR_X3_MIN_WGS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 512l; }();
+    if (ncols % 128 == 0) return dr_ceil_div((int)M, 128) * (long)(ncols / 128) >= min_wgs && (long)p.ksize * p.ksize * p.Kp >= 128;
     // 64-column blocks (the hourglass bottlenecks' 64 channels) on deep grids: 3x3 64->64 at 204 800 rows 165 -> 126 us, 1x1 128->64
     // 48.5 -> 43.6 (profiles/r05_x3_microbench.md); DR_X3_BN64=0 off
     static const bool bn64 = [] { const char* e = getenv("DR_X3_BN64"); return !(e && e[0] == '0'); }();
-    return bn64 && ncols % 64 == 0 && dr_ceil_div((int)M, 128) * (long)(ncols / 64) >= 1024 && (long)p.ksize * p.ksize * p.Kp >= 128;
+    return bn64 && ncols % 64 == 0 && dr_ceil_div((int)M, 128) * (long)(ncols / 64) >= 2 * min_wgs && (long)p.ksize * p.ksize * p.Kp >= 128;
 }
 
 // output rows per workgroup of the tile a problem gets

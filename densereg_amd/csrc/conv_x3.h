@@ -36,7 +36,12 @@ __host__ __device__ static inline void x3_split4(const float4 v, uint2& h0, uint
 }
 
 // LO = 1: the correction products in their own accumulator (below); LO = 0: all six products into one accumulator (measured variant)
-template <int BM, int BN, int LO = 1>
+// RING = 1: three LDS stages instead of two.  With two, a K-tile ends "ds_write the next tile, barrier, ds_read the fragments, wait":
+// the matrix cores idle through the barrier skew and an LDS round trip once per K-tile (768 cycles of MFMA work per wave).  With three,
+// tile t+2 is written while tile t is multiplied, the barrier sits in the MIDDLE of the tile's MFMA sequence (waves wait for each other
+// while their queued MFMAs execute), and the first fragments of tile t+1 -- in LDS since the previous barrier -- are fetched under the
+// last MFMAs of tile t, so the next tile starts on registers that are already there.  The global loads run one tile further ahead.
+template <int BM, int BN, int LO = 1, int RING = 0>
 __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvParams p) {
     constexpr int WM = 2, WN = 2, WK = 1, MF = 32, ABL = 0;
     constexpr int kWTM = BM / WM, kWTN = BN / WN, kTM = kWTM / 32, kTN = kWTN / 32;
@@ -50,8 +55,10 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
     __shared__ __attribute__((aligned(16))) float4 As1[3][BM][2];
     __shared__ __attribute__((aligned(16))) float4 Bs0[3][BN][2];
     __shared__ __attribute__((aligned(16))) float4 Bs1[3][BN][2];
-#define DR_AS(stage) ((stage) ? As1 : As0)
-#define DR_BS(stage) ((stage) ? Bs1 : Bs0)
+    __shared__ __attribute__((aligned(16))) float4 As2[3][BM][2];        // (RING only: an instantiation that never names them allocates nothing)
+    __shared__ __attribute__((aligned(16))) float4 Bs2[3][BN][2];
+#define DR_AS(stage) ((stage) == 0 ? As0 : (stage) == 1 ? As1 : As2)
+#define DR_BS(stage) ((stage) == 0 ? Bs0 : (stage) == 1 ? Bs1 : Bs2)
 
     DR_PIN_ARGS(p.x, p.x_cs, p.x_coff, p.Cin, p.B, p.H, p.W, p.ksize, p.w3, p.Kp, p.Np, p.rowmask, p.zeros, p.nfast, p.gx, p.gy, p.Ng);
     const int tid = threadIdx.x;
@@ -145,9 +152,11 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
             a_nv[i] = ok ? nv : 4;
         }
 #define X3_LOAD_B(i) *reinterpret_cast<const float4*>(b_ok[i] ? reinterpret_cast<const void*>(ld_w + b_off[i]) : reinterpret_cast<const void*>(p.zeros))
-        b_reg0 = X3_LOAD_B(0);
-        if constexpr (kBIters > 1) b_reg1 = X3_LOAD_B(1);
-        if constexpr (kBIters > 2) b_reg2 = X3_LOAD_B(2);
+        if constexpr (!RING) {                                             // (the ring copies the weight planes by LDS-DMA: dma_b below)
+            b_reg0 = X3_LOAD_B(0);
+            if constexpr (kBIters > 1) b_reg1 = X3_LOAD_B(1);
+            if constexpr (kBIters > 2) b_reg2 = X3_LOAD_B(2);
+        }
 #undef X3_LOAD_B
         ++ld_tap;
         if (++ld_dx > pad) { ld_dx = -pad; ++ld_dy; }
@@ -180,10 +189,32 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
             uint2* d2 = reinterpret_cast<uint2*>(&DR_AS(buf)[2][r][slot]) + (q & 1);
             *d0 = h0; *d1 = h1; *d2 = h2;
         }
-        float4* const bs = &DR_BS(buf)[0][0][0];
-        if (kBUnits % 256 == 0 || tid < kBUnits) bs[b_lds[0]] = b_reg0;
-        if constexpr (kBIters > 1) { if (kBUnits % 256 == 0 || tid + 256 < kBUnits) bs[b_lds[1]] = b_reg1; }
-        if constexpr (kBIters > 2) { if (kBUnits % 256 == 0 || tid + 512 < kBUnits) bs[b_lds[2]] = b_reg2; }
+        if constexpr (!RING) {
+            float4* const bs = &DR_BS(buf)[0][0][0];
+            if (kBUnits % 256 == 0 || tid < kBUnits) bs[b_lds[0]] = b_reg0;
+            if constexpr (kBIters > 1) { if (kBUnits % 256 == 0 || tid + 256 < kBUnits) bs[b_lds[1]] = b_reg1; }
+            if constexpr (kBIters > 2) { if (kBUnits % 256 == 0 || tid + 512 < kBUnits) bs[b_lds[2]] = b_reg2; }
+        }
+    };
+    // RING: the weight planes of a K-tile go HBM / L2 -> LDS without registers (global_load_lds_dwordx4): wave w copies the 64-unit
+    // chunks w, w + 4, ... of the tile's 3 * BN * 2 units; the LDS image is lane-linear, so the slot swizzle moves to the SOURCE
+    // address (unit L = (plane, row, physical slot) fetches logical slot = physical ^ ((row >> 3) & 1)).
+    unsigned bd_off[kBIters]; bool bd_ok[kBIters];
+#pragma unroll
+    for (int i = 0; i < kBIters; ++i) {
+        const int L = (wave + 4 * i) * 64 + lane;
+        const int pl = L / (BN * 2), within = L % (BN * 2), row = within >> 1, slot = (within & 1) ^ ((row >> 3) & 1);
+        bd_ok[i] = L < kBUnits && n0 + row < p.Np;
+        bd_off[i] = (unsigned)((pl * p.Np + n0 + row) * 16 + slot * 8);
+    }
+    const __bf16* dma_w = w3;
+    auto dma_b = [&](const int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < kBIters; ++i)
+            if ((wave + 4 * i) * 64 < kBUnits)                              // (wave-uniform)
+                dr_glds16(bd_ok[i] ? reinterpret_cast<const float*>(dma_w + bd_off[i]) : p.zeros,
+                          reinterpret_cast<float*>(&DR_BS(st)[0][0][0] + (wave + 4 * i) * 64));
+        dma_w += w_tile;
     };
 
     // Two accumulators per output tile: `acc` takes the leading products a0*b0, `lo` the five correction products (each <= 2^-8 of
@@ -200,36 +231,85 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
 #pragma unroll
             for (int r = 0; r < NR; ++r) { acc[i][j][r] = 0.f; if constexpr (LO) lo[i][j][r] = 0.f; }
 
+    const int lk = lane >> 5;
+    const int li = lane & 31;
+    const int fslot = lk ^ ((li >> 3) & 1);                                // this lane's LDS slot of every row it reads (rows = 32*t + li)
+    auto& LOACC = *reinterpret_cast<AccT(*)[kTM][kTN]>(LO ? &lo[0][0] : &acc[0][0]);
+#define X3_READ_A(d, pl, st) _Pragma("unroll") for (int i = 0; i < kTM; ++i) d[i] = DR_AS(st)[pl][wm * kWTM + i * 32 + li][fslot]
+#define X3_READ_B(d, pl, st) _Pragma("unroll") for (int j = 0; j < kTN; ++j) d[j] = DR_BS(st)[pl][wn * kWTN + j * 32 + li][fslot]
+#define X3_MMA(c, a, b)                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < kTM; ++i) _Pragma("unroll") for (int j = 0; j < kTN; ++j)                              \
+        c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dr_bf16x8, a[i]), __builtin_bit_cast(dr_bf16x8, b[j]), c[i][j], 0, 0, 0)
     const bool tail0 = CK > p.Cin;
+    if constexpr (RING) {
+        // ---- three stages: tiles 0 and 1 in LDS, tile 2's weights in LDS and its pixels in the staging registers, the planes 0 of
+        // tile 0 in a0 / b0.  Steady state of tile t (stage cur = t % 3):
+        //   read planes 2 of t | MFMA a0*b0, a2*b0, a0*b2 | read planes 1 of t | split + ds_write the pixels of t+2 (loaded after the
+        //   previous barrier) | wait for the weight copy of t+2 (issued after the previous barrier) | BARRIER | issue the pixel loads and
+        //   the weight copy of t+3 (into stage cur: every read of it was issued before the barrier) | MFMA a1*b0 | read b0 of t+1 |
+        //   MFMA a0*b1 | read a0 of t+1 | MFMA a1*b1
+        load_tile(); dma_b(0);
+        store_tile(0, tail0);
+        bool pend_tail = false;                                             // of the tile held in the staging registers
+        if (T_total > 1) { const bool tl = ld_kc + CK > p.Cin; load_tile(); dma_b(1); store_tile(1, tl); }
+        if (T_total > 2) { pend_tail = ld_kc + CK > p.Cin; load_tile(); dma_b(2); }
+#if !defined(DR_EMU)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the LDS-DMA copies have landed (a barrier alone does not say so)
+#endif
+        __syncthreads();
+        float4 a0[kTM], b0[kTN];
+        X3_READ_A(a0, 0, 0); X3_READ_B(b0, 0, 0);
+        // one K-tile: tile t in stage `cur`; more1 / more2 / more3: tiles t+1 / t+2 / t+3 exist
+        auto ring_tile = [&](const int cur, const int nxt, const int st, const bool more1, const bool more2, const bool more3) __attribute__((always_inline)) {
+            float4 ax[kTM], bx[kTN];
+            X3_READ_A(ax, 2, cur); X3_READ_B(bx, 2, cur);
+            X3_MMA(acc, a0, b0);                                           // starts at once: its operands were fetched under the previous tile
+            X3_MMA(LOACC, ax, b0);                                         // a2*b0
+            X3_MMA(LOACC, a0, bx);                                         // a0*b2
+            X3_READ_A(ax, 1, cur); X3_READ_B(bx, 1, cur);
+            if (more2) store_tile(st, pend_tail);                          // the pixels of tile t+2
+#if !defined(DR_EMU)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the weight copy of tile t+2 (nothing else is outstanding here)
+#endif
+            __syncthreads();                                                // (under the twelve MFMAs queued above)
+            if (more3) { pend_tail = ld_kc + CK > p.Cin; load_tile(); dma_b(cur); }
+            X3_MMA(LOACC, ax, b0);                                         // a1*b0: the last reader of b0
+            if (more1) { X3_READ_B(b0, 0, nxt); }
+            X3_MMA(LOACC, a0, bx);                                         // a0*b1: the last reader of a0
+            if (more1) { X3_READ_A(a0, 0, nxt); }
+            X3_MMA(LOACC, ax, bx);                                         // a1*b1
+        };
+        const int T3 = T_total - T_total % 3;
+        for (int t = 0; t < T3; t += 3) {
+            ring_tile(0, 1, 2, true, true, t + 3 < T_total);
+            ring_tile(1, 2, 0, true, t + 3 < T_total, t + 4 < T_total);
+            ring_tile(2, 0, 1, t + 3 < T_total, t + 4 < T_total, t + 5 < T_total);
+        }
+        if (T_total - T3 == 2) {
+            ring_tile(0, 1, 2, true, false, false);
+            ring_tile(1, 2, 0, false, false, false);
+        } else if (T_total - T3 == 1) {
+            ring_tile(0, 1, 2, false, false, false);
+        }
+        __syncthreads();                                                    // (the epilogue reuses stage 0 as scratch)
+    } else {
     load_tile();
     store_tile(0, tail0);
     __syncthreads();
 
-    const int lk = lane >> 5;
-    const int li = lane & 31;
-    const int fslot = lk ^ ((li >> 3) & 1);                                // this lane's LDS slot of every row it reads (rows = 32*t + li)
     auto k_tile = [&](const int buf, const bool more) __attribute__((always_inline)) {
         const bool was_tail = ld_kc + CK > p.Cin;                          // of the tile being fetched now
         if (more) load_tile();
         // fragments are read plane by plane, the planes 2 first: their registers are reused by the planes 1 (eight fragments live, not twelve)
         float4 a0[kTM], b0[kTN], ax[kTM], bx[kTN];
-        auto& LOACC = *reinterpret_cast<AccT(*)[kTM][kTN]>(LO ? &lo[0][0] : &acc[0][0]);
-#define X3_READ_A(d, pl) _Pragma("unroll") for (int i = 0; i < kTM; ++i) d[i] = DR_AS(buf)[pl][wm * kWTM + i * 32 + li][fslot]
-#define X3_READ_B(d, pl) _Pragma("unroll") for (int j = 0; j < kTN; ++j) d[j] = DR_BS(buf)[pl][wn * kWTN + j * 32 + li][fslot]
-#define X3_MMA(c, a, b)                                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < kTM; ++i) _Pragma("unroll") for (int j = 0; j < kTN; ++j)                              \
-        c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dr_bf16x8, a[i]), __builtin_bit_cast(dr_bf16x8, b[j]), c[i][j], 0, 0, 0)
-        X3_READ_A(a0, 0); X3_READ_B(b0, 0); X3_READ_A(ax, 2); X3_READ_B(bx, 2);
+        X3_READ_A(a0, 0, buf); X3_READ_B(b0, 0, buf); X3_READ_A(ax, 2, buf); X3_READ_B(bx, 2, buf);
         X3_MMA(LOACC, ax, b0);                                                // a2*b0
         X3_MMA(LOACC, a0, bx);                                                // a0*b2
-        X3_READ_A(ax, 1); X3_READ_B(bx, 1);
+        X3_READ_A(ax, 1, buf); X3_READ_B(bx, 1, buf);
         X3_MMA(acc, a0, b0);                                               // the leading products run while the planes 1 arrive
-        X3_MMA(LOACC, ax, bx);                                                // a1*b1
-        X3_MMA(LOACC, ax, b0);                                                // a1*b0
+        X3_MMA(LOACC, ax, b0);                                                // a1*b0   (the corrections in the ring's order: same bits)
         X3_MMA(LOACC, a0, bx);                                                // a0*b1
-#undef X3_READ_A
-#undef X3_READ_B
-#undef X3_MMA
+        X3_MMA(LOACC, ax, bx);                                                // a1*b1
         if (more) store_tile(buf ^ 1, was_tail);
         __syncthreads();
     };
@@ -239,6 +319,10 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
         k_tile(1, t + 2 < T_total);
     }
     if (T_total & 1) k_tile(0, false);
+    }
+#undef X3_READ_A
+#undef X3_READ_B
+#undef X3_MMA
 #pragma unroll
     for (int i = 0; i < kTM; ++i)
 #pragma unroll

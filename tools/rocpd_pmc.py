@@ -46,13 +46,15 @@ def short_name(n):
     m = re.search(r'conv_igemm_kernel<(\d+), (\d+)', n)
     if m:
         return 'conv_igemm_%sx%s' % (m.group(1), m.group(2))
+    if 'conv_x3_kernel' in n:                                      # every tile / variant of conv_x3.h is one profile row (net.h: KID_CONV_X3)
+        return 'conv_x3_128x128'
     if 'conv_splitk_kernel' in n:
         return 'conv_splitk_32x32'
     if 'conv_wgrad_row_kernel' in n:
         return 'conv_wgrad_row96'
     if 'conv_wgrad_group_kernel' in n:
         return 'conv_wgrad_group'
-    m = re.search(r'conv_wgrad(?:_bf16|_tr)?_kernel<(\d+)', n)
+    m = re.search(r'conv_wgrad(?:_bf16|_tr|_x3)?_kernel<(\d+)', n)
     if m:
         return 'conv_wgrad_%s' % m.group(1)
     if 'conv_wgrad16_kernel' in n:

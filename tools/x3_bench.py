@@ -21,12 +21,12 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     dbg = _lib.load_debug()
     ms = C.c_float()
-    print('| shape (HxW, Cin->Cout, k) at %d crops | fp32 MFMA us | TFLOP/s | x3 us | TFLOP/s | x3 one-acc us | TFLOP/s | x3 / fp32 |' % B)
+    print('| shape (HxW, Cin->Cout, k) at %d crops | fp32 MFMA us | TFLOP/s | x3 us | TFLOP/s | x3 two-stage us | TFLOP/s | x3 / fp32 |' % B)
     print('|---|---:|---:|---:|---:|---:|---:|---:|')
     for hw, cin, cout, k in SHAPES:
         fl = 2.0 * B * hw * hw * k * k * cin * cout
         row = []
-        for mode in (0, 2, 3):
+        for mode in (0, 2, 4):
             dbg.dr_dbg_force_x3(mode)
             rc = dbg.dr_dbg_conv_bench(B, hw, hw, cin, cout, k, -1, 0, 10, C.byref(ms))
             assert rc == 0, rc
@@ -44,11 +44,11 @@ def main():
         w = (rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
         yr, _ = ref_conv2d(x, w)
         out = []
-        for mode in (0, 2, 3):
+        for mode in (0, 2, 4, 3):
             be.dbg.dr_dbg_force_x3(mode)
             y = be.conv2d(x, w)
             e = np.abs(y - yr)
-            out.append('%s: max %.2e rms %.2e' % ({0: 'fp32', 2: 'x3', 3: 'x3 one-acc'}[mode], e.max() / np.abs(yr).max(), np.sqrt((e ** 2).mean()) / np.abs(yr).max()))
+            out.append('%s: max %.2e rms %.2e' % ({0: 'fp32', 2: 'x3 (ring)', 4: 'x3 two-stage', 3: 'x3 one-acc'}[mode], e.max() / np.abs(yr).max(), np.sqrt((e ** 2).mean()) / np.abs(yr).max()))
         be.dbg.dr_dbg_force_x3(-1)
         print('error vs fp64 (of the range), %dx%d %d->%d k%d B=%d: %s' % (hw, hw, cin, cout, k, b, ' | '.join(out)))
 

@@ -41,15 +41,18 @@ __host__ __device__ static inline void x3_split4(const float4 v, uint2& h0, uint
 // tile t+2 is written while tile t is multiplied, the barrier sits in the MIDDLE of the tile's MFMA sequence (waves wait for each other
 // while their queued MFMAs execute), and the first fragments of tile t+1 -- in LDS since the previous barrier -- are fetched under the
 // last MFMAs of tile t, so the next tile starts on registers that are already there.  The global loads run one tile further ahead.
-template <int BM, int BN, int LO = 1, int RING = 0>
-__global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvParams p) {
-    constexpr int WM = 2, WN = 2, WK = 1, MF = 32, ABL = 0;
+// NW = 8: 512 threads = 2 x 4 waves, wave tile (BM/2) x (BN/4) -- half the accumulators per wave (two tiles instead of four), so twice
+// the waves per SIMD fit the register file: more MFMA chains to interleave with the staging of the next tile.
+template <int BM, int BN, int LO = 1, int RING = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_kernel(const ConvParams p) {
+    constexpr int NT = NW * 64;                              // threads
+    constexpr int WM = 2, WN = NW / 2, WK = 1, MF = 32, ABL = 0;
     constexpr int kWTM = BM / WM, kWTN = BN / WN, kTM = kWTM / 32, kTN = kWTN / 32;
     static_assert(kWTM % 32 == 0 && kWTN % 32 == 0, "wave tile of whole 32x32 MFMA tiles");
     constexpr int CK = 16;                                   // input channels per K-tile
-    constexpr int kAIters = (BM * 4 + 255) / 256;            // float4 units (4 channels of a row) per thread
+    constexpr int kAIters = (BM * 4 + NT - 1) / NT;          // float4 units (4 channels of a row) per thread
     constexpr int kBUnits = 3 * BN * 2;                      // 16-byte units of the three weight planes
-    constexpr int kBIters = (kBUnits + 255) / 256;
+    constexpr int kBIters = (kBUnits + NT - 1) / NT;
     // one LDS object per stage (conv_igemm.h: the wait-count insertion tells stages apart by object); [plane][row][2 slots] of 16 bytes
     __shared__ __attribute__((aligned(16))) float4 As0[3][BM][2];
     __shared__ __attribute__((aligned(16))) float4 As1[3][BM][2];
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
     const int w_shift = __builtin_ctz((unsigned)p.W);
 #pragma unroll
     for (int i = 0; i < kAIters; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NT;
         const int row = idx >> 2;
         a_row[i] = row;
         a_q[i] = idx & 3;
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
     unsigned b_off[kBIters]; int b_lds[kBIters]; bool b_ok[kBIters];
 #pragma unroll
     for (int i = 0; i < kBIters; ++i) {
-        const int u = tid + i * 256;
+        const int u = tid + i * NT;
         const int pl = u / (BN * 2), within = u % (BN * 2), row = within >> 1, slot = within & 1;
         b_ok[i] = u < kBUnits && n0 + row < p.Np;
         b_off[i] = (unsigned)((pl * p.Np + n0 + row) * 16 + slot * 8);
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
             a_nv[i] = ok ? nv : 4;
         }
 #define X3_LOAD_B(i) *reinterpret_cast<const float4*>(b_ok[i] ? reinterpret_cast<const void*>(ld_w + b_off[i]) : reinterpret_cast<const void*>(p.zeros))
-        if constexpr (!RING) {                                             // (the ring copies the weight planes by LDS-DMA: dma_b below)
+        if constexpr (RING != 2) {                                         // (RING = 2 copies the weight planes by LDS-DMA: dma_b below)
             b_reg0 = X3_LOAD_B(0);
             if constexpr (kBIters > 1) b_reg1 = X3_LOAD_B(1);
             if constexpr (kBIters > 2) b_reg2 = X3_LOAD_B(2);
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
 #pragma unroll
         for (int i = 0; i < kAIters; ++i) {
             const int r = a_row[i], q = a_q[i];
-            if (BM * 4 < 256 * kAIters && r >= BM) continue;
+            if (BM * 4 < NT * kAIters && r >= BM) continue;
             float4 v = a_reg[i];
             if (ragged && was_tail) {
                 const int nv = a_nv[i];
@@ -189,11 +192,11 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
             uint2* d2 = reinterpret_cast<uint2*>(&DR_AS(buf)[2][r][slot]) + (q & 1);
             *d0 = h0; *d1 = h1; *d2 = h2;
         }
-        if constexpr (!RING) {
+        if constexpr (RING != 2) {
             float4* const bs = &DR_BS(buf)[0][0][0];
-            if (kBUnits % 256 == 0 || tid < kBUnits) bs[b_lds[0]] = b_reg0;
-            if constexpr (kBIters > 1) { if (kBUnits % 256 == 0 || tid + 256 < kBUnits) bs[b_lds[1]] = b_reg1; }
-            if constexpr (kBIters > 2) { if (kBUnits % 256 == 0 || tid + 512 < kBUnits) bs[b_lds[2]] = b_reg2; }
+            if (kBUnits % NT == 0 || tid < kBUnits) bs[b_lds[0]] = b_reg0;
+            if constexpr (kBIters > 1) { if (kBUnits % NT == 0 || tid + NT < kBUnits) bs[b_lds[1]] = b_reg1; }
+            if constexpr (kBIters > 2) { if (kBUnits % NT == 0 || tid + 2 * NT < kBUnits) bs[b_lds[2]] = b_reg2; }
         }
     };
     // RING: the weight planes of a K-tile go HBM / L2 -> LDS without registers (global_load_lds_dwordx4): wave w copies the 64-unit
@@ -202,18 +205,19 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
     unsigned bd_off[kBIters]; bool bd_ok[kBIters];
 #pragma unroll
     for (int i = 0; i < kBIters; ++i) {
-        const int L = (wave + 4 * i) * 64 + lane;
+        const int L = (wave + NW * i) * 64 + lane;
         const int pl = L / (BN * 2), within = L % (BN * 2), row = within >> 1, slot = (within & 1) ^ ((row >> 3) & 1);
         bd_ok[i] = L < kBUnits && n0 + row < p.Np;
         bd_off[i] = (unsigned)((pl * p.Np + n0 + row) * 16 + slot * 8);
     }
     const __bf16* dma_w = w3;
     auto dma_b = [&](const int st) __attribute__((always_inline)) {
+        if constexpr (RING != 2) return;
 #pragma unroll
         for (int i = 0; i < kBIters; ++i)
-            if ((wave + 4 * i) * 64 < kBUnits)                              // (wave-uniform)
+            if ((wave + NW * i) * 64 < kBUnits)                             // (wave-uniform)
                 dr_glds16(bd_ok[i] ? reinterpret_cast<const float*>(dma_w + bd_off[i]) : p.zeros,
-                          reinterpret_cast<float*>(&DR_BS(st)[0][0][0] + (wave + 4 * i) * 64));
+                          reinterpret_cast<float*>(&DR_BS(st)[0][0][0] + (wave + NW * i) * 64));
         dma_w += w_tile;
     };
 
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
         if (T_total > 1) { const bool tl = ld_kc + CK > p.Cin; load_tile(); dma_b(1); store_tile(1, tl); }
         if (T_total > 2) { pend_tail = ld_kc + CK > p.Cin; load_tile(); dma_b(2); }
 #if !defined(DR_EMU)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the LDS-DMA copies have landed (a barrier alone does not say so)
+        if constexpr (RING == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA copies have landed (a barrier alone does not say so)
 #endif
         __syncthreads();
         float4 a0[kTM], b0[kTN];
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
             X3_READ_A(ax, 1, cur); X3_READ_B(bx, 1, cur);
             if (more2) store_tile(st, pend_tail);                          // the pixels of tile t+2
 #if !defined(DR_EMU)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the weight copy of tile t+2 (nothing else is outstanding here)
+            if constexpr (RING == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight copy of tile t+2 (nothing else is outstanding here)
 #endif
             __syncthreads();                                                // (under the twelve MFMAs queued above)
             if (more3) { pend_tail = ld_kc + CK > p.Cin; load_tile(); dma_b(cur); }
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256, (LO ? 2 : 3)) void conv_x3_kernel(const ConvPa
             }
         }
         __syncthreads();
-        for (int e = tid; e < 2 * BN; e += 256) {
+        for (int e = tid; e < 2 * BN; e += NT) {
             const int which = e / BN, col = e % BN, n = n0 + col;
             double t = 0.0;
 #pragma unroll

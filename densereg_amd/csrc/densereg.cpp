@@ -205,9 +205,11 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         const bool bn64 = ncols % 128 != 0 && ncols % 64 == 0;               // 64-column blocks where 128 would compute padding
         dim3 grid(dr_ceil_div((int)M, 128), dr_ceil_div(ncols, bn64 ? 64 : 128));
         q.gx = (int)grid.x; q.gy = (int)grid.y;
-        // variants (DR_X3_VARIANT bit 0: one accumulator, bit 1: two LDS stages instead of the ring; dr_dbg_force_x3 3 / 4 select the same)
+        // variants (DR_X3_VARIANT bit 0: one accumulator, bit 1: three-stage LDS ring, bit 2: four waves of 64x64 instead of eight of 64x32;
+        // dr_dbg_force_x3 3 / 4 / 5 select the same)
         const bool one_acc = (variant & 1) || g_dbg_x3 == 3;
-        const bool ring = !((variant & 2) || g_dbg_x3 == 4) && !one_acc;
+        const bool ring = ((variant & 2) || g_dbg_x3 == 4) && !one_acc;          // (measured slower than two stages: profiles/r05_experiments.md)
+        const bool w4 = (variant & 4) || g_dbg_x3 == 5 || one_acc || ring;
         if (bn64) {
             if (one_acc) DR_LAUNCH((conv_x3_kernel<128, 64, 0>), grid, dim3(256), 0, s, q);
             else if (ring) DR_LAUNCH((conv_x3_kernel<128, 64, 1, 1>), grid, dim3(256), 0, s, q);
@@ -215,7 +217,8 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         } else {
             if (one_acc) DR_LAUNCH((conv_x3_kernel<128, 128, 0>), grid, dim3(256), 0, s, q);
             else if (ring) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 1>), grid, dim3(256), 0, s, q);
-            else DR_LAUNCH((conv_x3_kernel<128, 128, 1>), grid, dim3(256), 0, s, q);
+            else if (w4) DR_LAUNCH((conv_x3_kernel<128, 128, 1>), grid, dim3(256), 0, s, q);
+            else DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8>), grid, dim3(512), 0, s, q);
         }
         return 0;
     }

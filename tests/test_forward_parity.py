@@ -106,7 +106,7 @@ def test_conv_x3_fp32_accurate_products_on_the_bf16_matrix_cores(be, case):
     mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if k == 1 else None
     yr, raw = ref_conv2d(x, w, scale, shift, True, res, mask, -0.5)
     outs = {}
-    for mode in (0, 2, 4):                                   # fp32 matrix cores | x3 (three-stage LDS ring, the default) | x3 with two stages
+    for mode in (0, 2, 4, 5):                                # fp32 matrix cores | x3 (default: eight waves) | three-stage LDS ring | four waves
         try:
             assert be.dbg.dr_dbg_force_x3(mode) == 0
             outs[mode] = be.conv2d(x, w, scale, shift, True, res, mask, -0.5, want_stats=True)
@@ -120,8 +120,9 @@ def test_conv_x3_fp32_accurate_products_on_the_bf16_matrix_cores(be, case):
     # measured on MI355X (profiles/r05_x3_microbench.md): rms equal to the fp32 kernel's (4.2e-8 vs 4.0e-8 on 3x3 256->256, 1.9e-8 vs
     # 5.5e-8 on 1x1 512->512), the maximum within 3x; the emulator's strictly sequential fma chain makes the fp32 kernel look better
     assert r3 < 3 * r32 + 2e-8 and e3 < 6 * e32 + 2e-7, (e3, e32, r3, r32)
-    # the ring and the two-stage kernel multiply the same planes in the same K order: the same bits, whatever the staging
+    # every variant multiplies the same planes in the same K order: the same bits, whatever the staging and the wave layout
     np.testing.assert_array_equal(outs[2][0], outs[4][0])
+    np.testing.assert_array_equal(outs[2][0], outs[5][0])
     for y, st in outs.values():
         np.testing.assert_allclose(st[0], raw.sum((0, 1, 2)), rtol=1e-4, atol=1e-4 * float(np.abs(raw).max()) * raw[..., 0].size ** 0.5)
         np.testing.assert_allclose(st[1], (raw ** 2).sum((0, 1, 2)), rtol=1e-4)

@@ -21,19 +21,19 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     dbg = _lib.load_debug()
     ms = C.c_float()
-    print('| shape (HxW, Cin->Cout, k) at %d crops | fp32 MFMA us | TFLOP/s | x3 us | TFLOP/s | x3 two-stage us | TFLOP/s | x3 / fp32 |' % B)
-    print('|---|---:|---:|---:|---:|---:|---:|---:|')
+    print('| shape (HxW, Cin->Cout, k) at %d crops | fp32 MFMA us | TFLOP/s | x3 us | TFLOP/s | x3 four waves us | TFLOP/s | x3 ring us | TFLOP/s | x3 / fp32 |' % B)
+    print('|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|')
     for hw, cin, cout, k in SHAPES:
         fl = 2.0 * B * hw * hw * k * k * cin * cout
         row = []
-        for mode in (0, 2, 4):
+        for mode in (0, 2, 5, 4):
             dbg.dr_dbg_force_x3(mode)
             rc = dbg.dr_dbg_conv_bench(B, hw, hw, cin, cout, k, -1, 0, 10, C.byref(ms))
             assert rc == 0, rc
             row.append(ms.value * 1e3)
         dbg.dr_dbg_force_x3(-1)
-        print('| %dx%d %d->%d k%d | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.2fx |' % (
-            hw, hw, cin, cout, k, row[0], fl / row[0] / 1e6, row[1], fl / row[1] / 1e6, row[2], fl / row[2] / 1e6, row[0] / row[1]))
+        print('| %dx%d %d->%d k%d | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.2fx |' % (
+            hw, hw, cin, cout, k, row[0], fl / row[0] / 1e6, row[1], fl / row[1] / 1e6, row[2], fl / row[2] / 1e6, row[3], fl / row[3] / 1e6, row[0] / row[1]))
         sys.stdout.flush()
     # errors against fp64 on one big layer (network-like operands: post-ReLU activations, He weights)
     from tests.common import GpuBackend, ref_conv2d
@@ -44,11 +44,11 @@ def main():
         w = (rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
         yr, _ = ref_conv2d(x, w)
         out = []
-        for mode in (0, 2, 4, 3):
+        for mode in (0, 2, 5, 3):
             be.dbg.dr_dbg_force_x3(mode)
             y = be.conv2d(x, w)
             e = np.abs(y - yr)
-            out.append('%s: max %.2e rms %.2e' % ({0: 'fp32', 2: 'x3 (ring)', 4: 'x3 two-stage', 3: 'x3 one-acc'}[mode], e.max() / np.abs(yr).max(), np.sqrt((e ** 2).mean()) / np.abs(yr).max()))
+            out.append('%s: max %.2e rms %.2e' % ({0: 'fp32', 2: 'x3', 5: 'x3 four waves', 3: 'x3 one-acc'}[mode], e.max() / np.abs(yr).max(), np.sqrt((e ** 2).mean()) / np.abs(yr).max()))
         be.dbg.dr_dbg_force_x3(-1)
         print('error vs fp64 (of the range), %dx%d %d->%d k%d B=%d: %s' % (hw, hw, cin, cout, k, b, ' | '.join(out)))
 

@@ -353,8 +353,8 @@ def main():
             # conv_x3.h forms every fp32 product from SIX bf16 products on v_mfma_f32_32x32x16_bf16: its ceiling is the dense bf16
             # matrix-core rate / 6 (416.7 TFLOP/s of algorithmic fp32-accurate FLOPs), not the fp32-MFMA rate it replaces
             def peak_of(name):
-                return (PEAK_BF16_MFMA_TFLOPS / 6.0, 'bf16 MFMA dense %.0f TFLOP/s / 6 products per fp32-accurate product (conv_x3.h)' % PEAK_BF16_MFMA_TFLOPS) \
-                    if name.startswith('conv_x3') else (peak, ('bf16' if bf16 else 'fp32') + ' MFMA dense')
+                return (PEAK_BF16_MFMA_TFLOPS / 6.0, 'bf16 MFMA dense %.0f TFLOP/s / 6 products per fp32-accurate product (conv_x3.h, conv_wgrad_x3.h)' % PEAK_BF16_MFMA_TFLOPS) \
+                    if name.startswith(('conv_x3', 'conv_wgrad_x3')) else (peak, ('bf16' if bf16 else 'fp32') + ' MFMA dense')
             peak_dom, peak_basis = peak_of(dom['name'])
             pmc_mode = mode + ('_bf16' if bf16 else '') + ('' if (S, F, HW) == (2, 128, 128) else '_s%df%dhw%d' % (S, F, HW))
             traffic, traffic_prov = pmc_traffic(pmc_mode, dom['name'])

@@ -43,10 +43,12 @@ __host__ __device__ static inline void x3_split4(const float4 v, uint2& h0, uint
 // last MFMAs of tile t, so the next tile starts on registers that are already there.  The global loads run one tile further ahead.
 // NW = 8: 512 threads = 2 x 4 waves, wave tile (BM/2) x (BN/4) -- half the accumulators per wave (two tiles instead of four), so twice
 // the waves per SIMD fit the register file: more MFMA chains to interleave with the staging of the next tile.
-template <int BM, int BN, int LO = 1, int RING = 0, int NW = 4>
+// WM_ = 4 (with NW = 4): the waves split the rows only, each owns ALL BN columns -- the 96-column tile of the 65..96-channel layers
+// (three column tiles per wave; a 2 x 2 layout would need 64-column multiples).
+template <int BM, int BN, int LO = 1, int RING = 0, int NW = 4, int WM_ = 2>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_kernel(const ConvParams p) {
     constexpr int NT = NW * 64;                              // threads
-    constexpr int WM = 2, WN = NW / 2, WK = 1, MF = 32, ABL = 0;
+    constexpr int WM = WM_, WN = NW / WM_, WK = 1, MF = 32, ABL = 0;
     constexpr int kWTM = BM / WM, kWTN = BN / WN, kTM = kWTM / 32, kTN = kWTN / 32;
     static_assert(kWTM % 32 == 0 && kWTN % 32 == 0, "wave tile of whole 32x32 MFMA tiles");
     constexpr int CK = 16;                                   // input channels per K-tile

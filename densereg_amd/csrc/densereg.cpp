@@ -177,6 +177,10 @@ bool conv_use_x3(const ConvParams& p) {
     // 64-column blocks (the hourglass bottlenecks' 64 channels) on deep grids: 3x3 64->64 at 204 800 rows 165 -> 126 us, 1x1 128->64
     // 48.5 -> 43.6 (profiles/r05_x3_microbench.md); DR_X3_BN64=0 off
     static const bool bn64 = [] { const char* e = getenv("DR_X3_BN64"); return !(e && e[0] == '0'); }();
+    // one 96-column block for the 65..96-channel layers (the hm3 / um-tower residuals and their input gradients) on deep grids;
+    // DR_X3_BN96=0 leaves them on the fp32 16-column tiles
+    static const bool bn96 = [] { const char* e = getenv("DR_X3_BN96"); return !(e && e[0] == '0'); }();
+    if (ncols == 96) return bn96 && dr_ceil_div((int)M, 128) >= 2 * min_wgs && (long)p.ksize * p.ksize * p.Kp >= 128;
     return bn64 && ncols % 64 == 0 && dr_ceil_div((int)M, 128) * (long)(ncols / 64) >= 2 * min_wgs && (long)p.ksize * p.ksize * p.Kp >= 128;
 }
 
@@ -202,15 +206,18 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         ConvParams q = p;
         q.nfast = nfast;
         const int ncols = p.Ng > 0 ? p.Ng : p.Np;
-        const bool bn64 = ncols % 128 != 0 && ncols % 64 == 0;               // 64-column blocks where 128 would compute padding
-        dim3 grid(dr_ceil_div((int)M, 128), dr_ceil_div(ncols, bn64 ? 64 : 128));
+        const bool bn96 = ncols == 96;                                       // the 65..96-channel layers: one 96-column block
+        const bool bn64 = !bn96 && ncols % 128 != 0 && ncols % 64 == 0;      // 64-column blocks where 128 would compute padding
+        dim3 grid(dr_ceil_div((int)M, 128), bn96 ? 1 : dr_ceil_div(ncols, bn64 ? 64 : 128));
         q.gx = (int)grid.x; q.gy = (int)grid.y;
         // variants (DR_X3_VARIANT bit 0: one accumulator, bit 1: three-stage LDS ring, bit 2: four waves of 64x64 instead of eight of 64x32;
         // dr_dbg_force_x3 3 / 4 / 5 select the same)
         const bool one_acc = (variant & 1) || g_dbg_x3 == 3;
         const bool ring = ((variant & 2) || g_dbg_x3 == 4) && !one_acc;          // (measured slower than two stages: profiles/r05_experiments.md)
         const bool w4 = (variant & 4) || g_dbg_x3 == 5 || one_acc || ring;
-        if (bn64) {
+        if (bn96) {
+            DR_LAUNCH((conv_x3_kernel<128, 96, 1, 0, 4, 4>), grid, dim3(256), 0, s, q);
+        } else if (bn64) {
             if (one_acc) DR_LAUNCH((conv_x3_kernel<128, 64, 0>), grid, dim3(256), 0, s, q);
             else if (ring) DR_LAUNCH((conv_x3_kernel<128, 64, 1, 1>), grid, dim3(256), 0, s, q);
             else DR_LAUNCH((conv_x3_kernel<128, 64, 1>), grid, dim3(256), 0, s, q);

@@ -54,7 +54,10 @@ def short_name(n):
         return 'conv_wgrad_row96'
     if 'conv_wgrad_group_kernel' in n:
         return 'conv_wgrad_group'
-    m = re.search(r'conv_wgrad(?:_bf16|_tr|_x3)?_kernel<(\d+)', n)
+    m = re.search(r'conv_wgrad_x3_kernel<(\d+)', n)
+    if m:
+        return 'conv_wgrad_x3_%s' % m.group(1)
+    m = re.search(r'conv_wgrad(?:_bf16|_tr)?_kernel<(\d+)', n)
     if m:
         return 'conv_wgrad_%s' % m.group(1)
     if 'conv_wgrad16_kernel' in n:

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from densereg_amd import _lib  # noqa: E402
 
 SHAPES = [(32, 256, 256, 3), (32, 128, 128, 3), (32, 512, 512, 1), (32, 512, 256, 1), (32, 256, 512, 1), (32, 256, 128, 1), (32, 128, 256, 1),
-          (32, 128, 128, 1), (32, 515, 512, 1), (32, 64, 64, 3), (32, 128, 64, 1), (32, 64, 128, 1), (16, 64, 64, 3), (16, 128, 64, 1)]
+          (32, 128, 128, 1), (32, 515, 512, 1), (32, 78, 78, 3), (32, 65, 65, 3), (32, 156, 78, 1), (32, 131, 65, 1), (32, 64, 64, 3), (32, 128, 64, 1), (32, 64, 128, 1), (16, 64, 64, 3), (16, 128, 64, 1)]
 
 
 def main():

@@ -15,15 +15,11 @@
 
 namespace dr {
 
-// NW = 8 (T = 128): 512 threads = 2 x 4 waves, wave tile 64 input x 32 output channels -- half the accumulators per wave, four waves per
-// SIMD instead of two; the lower four waves stage x, the upper four g (one chunk per thread).
-template <int T, int NW = 4>
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : T == 128 ? 2 : 4)) void conv_wgrad_x3_kernel(const WgradParams p) {
+template <int T>
+__global__ __launch_bounds__(256, (T == 128 ? 2 : 4)) void conv_wgrad_x3_kernel(const WgradParams p) {
     constexpr int BKP = 16;                // pixels per step
-    constexpr int WT = T / 2;              // wave tile along Cin
-    constexpr int WTN = T / (NW / 2);      // ... along Cout
-    constexpr int TM = WT / 32, TN = WTN / 32;
-    static_assert(NW == 4 || (NW == 8 && T == 128), "eight waves: the 128-channel tile");
+    constexpr int WT = T / 2;              // wave tile
+    constexpr int TM = WT / 32;
     constexpr int RS = T + 16;             // LDS row stride in bf16 elements (conv_wgrad_tr.h: the 4 rows of a transpose block on 4 bank groups)
     constexpr int C8N = T / 8;             // 8-channel chunks per pixel row
     constexpr int CHUNKS = BKP * C8N;      // chunks per operand and step: 256 (T = 128) or 128 (T = 64: the upper half of the threads stage nothing)
@@ -36,7 +32,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : T == 128 ? 2 : 4)) void con
 #define DR_GS(st) ((st) ? Gs1 : Gs0)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / (NW / 2), wn = wave % (NW / 2);
+    const int wm = wave >> 1, wn = wave & 1;
     const int lk = lane >> 5, li = lane & 31;
     const int co_tiles = dr_ceil_div(p.Cout, T);
     const int taps = p.ksize * p.ksize;
@@ -66,12 +62,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : T == 128 ? 2 : 4)) void con
     const bool border = p.ksize > 1;
 
     // ---- staging: chunk = 8 channels of one pixel, one per thread and operand ----------------------------------------------------
-    const bool stage_x = NW == 8 ? tid < 256 : tid < CHUNKS, stage_g = NW == 8 ? tid >= 256 : tid < CHUNKS;
-    const bool stager = stage_x || stage_g;
+    const bool stager = tid < CHUNKS;
     const int c_pix = (tid % CHUNKS) / C8N, c_ch = ((tid % CHUNKS) % C8N) * 8;
     const int xl = p.Cin - (ci0 + c_ch), gl = p.Cout - (co0 + c_ch);
-    const int x_nv = !stage_x ? 0 : xl < 0 ? 0 : (xl > 8 ? 8 : xl);       // valid channels of the chunk (0..8)
-    const int g_nv = !stage_g ? 0 : gl < 0 ? 0 : (gl > 8 ? 8 : gl);
+    const int x_nv = !stager ? 0 : xl < 0 ? 0 : (xl > 8 ? 8 : xl);        // valid channels of the chunk (0..8)
+    const int g_nv = !stager ? 0 : gl < 0 ? 0 : (gl > 8 ? 8 : gl);
     float4 xa, xb, ga, gb;                                                // channels 0..3 / 4..7 of the chunk
     bool x_ok = false, g_ok = false;
     int next_step = 0;
@@ -95,14 +90,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : T == 128 ? 2 : 4)) void con
         const unsigned go = okg ? (unsigned)m * (unsigned)p.g_cs + (unsigned)(p.g_coff + co0 + c_ch) : 0u;
         // one batch of unconditional loads (a dead chunk reads the tensor base and is zeroed at store time); the second half of a
         // chunk is only fetched where the row has it (a chunk of <= 4 valid channels ends at the row's last 16 bytes)
-        if (NW == 4 || stage_x) {                                            // (eight waves: wave-uniform, a thread stages one operand)
-            xa = *reinterpret_cast<const float4*>(p.x + xo);
-            xb = *reinterpret_cast<const float4*>(p.x + (x_nv > 4 ? xo + 4u : xo));
-        }
-        if (NW == 4 || stage_g) {
-            ga = *reinterpret_cast<const float4*>(p.g + go);
-            gb = *reinterpret_cast<const float4*>(p.g + (g_nv > 4 ? go + 4u : go));
-        }
+        xa = *reinterpret_cast<const float4*>(p.x + xo);
+        xb = *reinterpret_cast<const float4*>(p.x + (x_nv > 4 ? xo + 4u : xo));
+        ga = *reinterpret_cast<const float4*>(p.g + go);
+        gb = *reinterpret_cast<const float4*>(p.g + (g_nv > 4 ? go + 4u : go));
         x_ok = okx && !(p.rowmask && mk < p.mask_thresh);
         g_ok = okg;
     };
@@ -121,25 +112,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : T == 128 ? 2 : 4)) void con
     auto store = [&](const int buf) __attribute__((always_inline)) {
         if (CHUNKS < 256 && !stager) return;
         float4 h0, h1, h2;
-        if (NW == 4 || stage_x) {
-            split8(xa, xb, x_nv, x_ok, h0, h1, h2);
-            *reinterpret_cast<float4*>(&DR_XS(buf)[0][c_pix][c_ch]) = h0;
-            *reinterpret_cast<float4*>(&DR_XS(buf)[1][c_pix][c_ch]) = h1;
-            *reinterpret_cast<float4*>(&DR_XS(buf)[2][c_pix][c_ch]) = h2;
-        }
-        if (NW == 4 || stage_g) {
-            split8(ga, gb, g_nv, g_ok, h0, h1, h2);
-            *reinterpret_cast<float4*>(&DR_GS(buf)[0][c_pix][c_ch]) = h0;
-            *reinterpret_cast<float4*>(&DR_GS(buf)[1][c_pix][c_ch]) = h1;
-            *reinterpret_cast<float4*>(&DR_GS(buf)[2][c_pix][c_ch]) = h2;
-        }
+        split8(xa, xb, x_nv, x_ok, h0, h1, h2);
+        *reinterpret_cast<float4*>(&DR_XS(buf)[0][c_pix][c_ch]) = h0;
+        *reinterpret_cast<float4*>(&DR_XS(buf)[1][c_pix][c_ch]) = h1;
+        *reinterpret_cast<float4*>(&DR_XS(buf)[2][c_pix][c_ch]) = h2;
+        split8(ga, gb, g_nv, g_ok, h0, h1, h2);
+        *reinterpret_cast<float4*>(&DR_GS(buf)[0][c_pix][c_ch]) = h0;
+        *reinterpret_cast<float4*>(&DR_GS(buf)[1][c_pix][c_ch]) = h1;
+        *reinterpret_cast<float4*>(&DR_GS(buf)[2][c_pix][c_ch]) = h2;
     };
 
-    dr_f32x16 acc[TM][TN], lo[TM][TN];                                    // leading products / the five corrections (conv_x3.h)
+    dr_f32x16 acc[TM][TM], lo[TM][TM];                                    // leading products / the five corrections (conv_x3.h)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TM; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = lo[i][j][r] = 0.f;
 
@@ -148,8 +135,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : T == 128 ? 2 : 4)) void con
         store(0);
     }
     __syncthreads();
-    const int na_ = (p.Cin - (ci0 + wm * WT) + 31) / 32, nb_ = (p.Cout - (co0 + wn * WTN) + 31) / 32;
-    const int na = na_ < 0 ? 0 : (na_ > TM ? TM : na_), nb = nb_ < 0 ? 0 : (nb_ > TN ? TN : nb_);
+    const int na_ = (p.Cin - (ci0 + wm * WT) + 31) / 32, nb_ = (p.Cout - (co0 + wn * WT) + 31) / 32;
+    const int na = na_ < 0 ? 0 : (na_ > TM ? TM : na_), nb = nb_ < 0 ? 0 : (nb_ > TM ? TM : nb_);
     // transpose-read addressing (conv_wgrad_tr.h): lane = 16 * grp + i16; grp & 1 selects the 16-channel half of the 32-channel MFMA
     // tile, grp >> 1 = lk the k half; the lane SUPPLIES chunk i16 of the [4 pixels][16 channels] block
     const int i16 = lane & 15, half = (lane >> 4) & 1;
@@ -157,24 +144,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : T == 128 ? 2 : 4)) void con
     const int t_ch = 16 * half + 4 * (i16 & 3);
     auto k_step = [&](const int buf, const bool more) __attribute__((always_inline)) {
         if (more) load();
-        dr_bf16x8 a[3][TM], b[3][TN];
+        dr_bf16x8 a[3][TM], b[3][TM];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 const uint2 a0 = dr_lds_read_tr16(&DR_XS(buf)[pl][t_pix][wm * WT + 32 * t + t_ch]);
                 const uint2 a1 = dr_lds_read_tr16(&DR_XS(buf)[pl][t_pix + 4][wm * WT + 32 * t + t_ch]);
+                const uint2 b0 = dr_lds_read_tr16(&DR_GS(buf)[pl][t_pix][wn * WT + 32 * t + t_ch]);
+                const uint2 b1 = dr_lds_read_tr16(&DR_GS(buf)[pl][t_pix + 4][wn * WT + 32 * t + t_ch]);
                 a[pl][t] = __builtin_bit_cast(dr_bf16x8, make_float4(__builtin_bit_cast(float, a0.x), __builtin_bit_cast(float, a0.y),
                                                                        __builtin_bit_cast(float, a1.x), __builtin_bit_cast(float, a1.y)));
-            }
-#pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const uint2 b0 = dr_lds_read_tr16(&DR_GS(buf)[pl][t_pix][wn * WTN + 32 * t + t_ch]);
-                const uint2 b1 = dr_lds_read_tr16(&DR_GS(buf)[pl][t_pix + 4][wn * WTN + 32 * t + t_ch]);
                 b[pl][t] = __builtin_bit_cast(dr_bf16x8, make_float4(__builtin_bit_cast(float, b0.x), __builtin_bit_cast(float, b0.y),
                                                                        __builtin_bit_cast(float, b1.x), __builtin_bit_cast(float, b1.y)));
             }
-        }
         auto mf = [&](auto NA, auto NB) __attribute__((always_inline)) {
 #define X3W_MMA(c, pa, pb)                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < decltype(NA)::value; ++i) _Pragma("unroll") for (int j = 0; j < decltype(NB)::value; ++j) \
@@ -185,12 +168,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : T == 128 ? 2 : 4)) void con
         };
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
-        if constexpr (TM == 2 && TN == 1) {
-            if (nb == 1) {
-                if (na == 2) mf(I2{}, I1{});
-                else if (na == 1) mf(I1{}, I1{});
-            }
-        } else if constexpr (TM == 2) {
+        if constexpr (TM == 2) {
             if (na == 2) {
                 if (nb == 2) mf(I2{}, I2{});
                 else if (nb == 1) mf(I2{}, I1{});
@@ -214,8 +192,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : T == 128 ? 2 : 4)) void con
     // partial[split][tap][ci][co]; D: row = (r&3)+8*(r>>2)+4*lk (ci), col = li (co)
     float* dst = p.partial + ((long)split * taps + tap) * p.Cin * p.Cout;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = co0 + wn * WTN + 32 * j + li;
+    for (int j = 0; j < TM; ++j) {
+        const int co = co0 + wn * WT + 32 * j + li;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll

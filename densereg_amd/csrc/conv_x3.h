@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
     constexpr int EP_TM = kTM, EP_TN = kTN;
     const int ep_m0 = m0 + wm * kWTM, ep_n0 = n0 + wn * kWTN;
     const unsigned ep_rows = 0xFFFFu;
-    constexpr int EP_BATCH_ROWS = 8;
+    constexpr int EP_BATCH_ROWS = NW == 8 ? 4 : 8;          // (eight waves live on 128 registers: four rows of epilogue loads in flight)
     constexpr int EP_TS = MF, EP_NR = NR;
     const int ep_lg = lk, ep_lc = li;
     {

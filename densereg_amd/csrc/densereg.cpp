@@ -213,17 +213,25 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         // variants (DR_X3_VARIANT bit 0: one accumulator, bit 1: three-stage LDS ring, bit 2: four waves of 64x64 instead of eight of 64x32;
         // dr_dbg_force_x3 3 / 4 / 5 select the same)
         const bool one_acc = (variant & 1) || g_dbg_x3 == 3;
-        const bool ring = ((variant & 2) || g_dbg_x3 == 4) && !one_acc;          // (measured slower than two stages: profiles/r05_experiments.md)
+#if defined(DR_DEBUG_HOOKS)
+        const bool ring = ((variant & 2) || g_dbg_x3 == 4) && !one_acc;          // (measured slower than two stages: profiles/r05_experiments.md;
+#else                                                                            //  instantiated in the test / bench library only)
+        const bool ring = false;
+#endif
         const bool w4 = (variant & 4) || g_dbg_x3 == 5 || one_acc || ring;
         if (bn96) {
             DR_LAUNCH((conv_x3_kernel<128, 96, 1, 0, 4, 4>), grid, dim3(256), 0, s, q);
         } else if (bn64) {
             if (one_acc) DR_LAUNCH((conv_x3_kernel<128, 64, 0>), grid, dim3(256), 0, s, q);
+#if defined(DR_DEBUG_HOOKS)
             else if (ring) DR_LAUNCH((conv_x3_kernel<128, 64, 1, 1>), grid, dim3(256), 0, s, q);
+#endif
             else DR_LAUNCH((conv_x3_kernel<128, 64, 1>), grid, dim3(256), 0, s, q);
         } else {
             if (one_acc) DR_LAUNCH((conv_x3_kernel<128, 128, 0>), grid, dim3(256), 0, s, q);
+#if defined(DR_DEBUG_HOOKS)
             else if (ring) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 1>), grid, dim3(256), 0, s, q);
+#endif
             else if (w4) DR_LAUNCH((conv_x3_kernel<128, 128, 1>), grid, dim3(256), 0, s, q);
             else DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8>), grid, dim3(512), 0, s, q);
         }

@@ -32,3 +32,7 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy():
         assert occ.get(name) == 5, (name, occ.get(name))
     assert occ.get('dr::conv_igemm_kernel<64, 80, 4, 1, 0, 16, 0, 0, 1, 0, 16>', 0) >= 5
     assert occ['dr::conv_wgrad_kernel<128>'] >= 3 and occ['dr::bn_train_apply_kernel<0, 0>'] >= 5
+    # the x3 kernels (round 5): eight waves per workgroup need four waves per SIMD = at most 128 registers; the four-wave forms two
+    assert occ.get('dr::conv_x3_kernel<128, 128, 1, 0, 8, 2>') == 4, occ.get('dr::conv_x3_kernel<128, 128, 1, 0, 8, 2>')
+    assert occ.get('dr::conv_x3_kernel<128, 96, 1, 0, 4, 4>', 0) >= 2 and occ.get('dr::conv_x3_kernel<128, 64, 1, 0, 4, 2>', 0) >= 3
+    assert occ.get('dr::conv_wgrad_x3_kernel<128, 4>', occ.get('dr::conv_wgrad_x3_kernel<128>', 0)) >= 2

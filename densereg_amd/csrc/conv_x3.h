@@ -24,18 +24,24 @@
 
 namespace dr {
 
-// fp32 x 8 -> three planes of 8 bf16 (as float4 bit patterns); used by the weight packer on 1 element too
+// four fp32 -> three planes of four bf16 (two words per plane).  Every level is two packed conversions (v_cvt_pk_bf16_f32, round to
+// nearest even); the rounded values come back as fp32 by a shift / a mask of the packed words (left to the compiler the round trip
+// was four more single conversions per level: 14 conversions per call instead of 6)
+typedef float dr_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 dr_bf16x2 __attribute__((ext_vector_type(2)));
+__host__ __device__ static inline unsigned x3_pack2(float a, float b) {
+    const dr_f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, dr_bf16x2));
+}
 __host__ __device__ static inline void x3_split4(const float4 v, uint2& h0, uint2& h1, uint2& h2) {
-    const dr_f32x4 f = {v.x, v.y, v.z, v.w};
-    const dr_bf16x4 b0 = __builtin_convertvector(f, dr_bf16x4);
-    const dr_f32x4 r1 = f - __builtin_convertvector(b0, dr_f32x4);
-    const dr_bf16x4 b1 = __builtin_convertvector(r1, dr_bf16x4);
-    const dr_f32x4 r2 = r1 - __builtin_convertvector(b1, dr_f32x4);
-    const dr_bf16x4 b2 = __builtin_convertvector(r2, dr_bf16x4);
-    h0 = __builtin_bit_cast(uint2, b0); h1 = __builtin_bit_cast(uint2, b1); h2 = __builtin_bit_cast(uint2, b2);
+    auto lo = [](unsigned w) { return __builtin_bit_cast(float, w << 16); };
+    auto hi = [](unsigned w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); };
+    h0 = make_uint2(x3_pack2(v.x, v.y), x3_pack2(v.z, v.w));
+    const float r0 = v.x - lo(h0.x), r1 = v.y - hi(h0.x), r2 = v.z - lo(h0.y), r3 = v.w - hi(h0.y);
+    h1 = make_uint2(x3_pack2(r0, r1), x3_pack2(r2, r3));
+    h2 = make_uint2(x3_pack2(r0 - lo(h1.x), r1 - hi(h1.x)), x3_pack2(r2 - lo(h1.y), r3 - hi(h1.y)));
 }
 
-// LO = 1: the correction products in their own accumulator (below); LO = 0: all six products into one accumulator (measured variant)
 // RING = 1: three LDS stages instead of two.  With two, a K-tile ends "ds_write the next tile, barrier, ds_read the fragments, wait":
 // the matrix cores idle through the barrier skew and an LDS round trip once per K-tile (768 cycles of MFMA work per wave).  With three,
 // tile t+2 is written while tile t is multiplied, the barrier sits in the MIDDLE of the tile's MFMA sequence (waves wait for each other

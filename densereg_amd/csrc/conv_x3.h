@@ -24,9 +24,11 @@
 
 namespace dr {
 
-// four fp32 -> three planes of four bf16 (two words per plane).  Every level is two packed conversions (v_cvt_pk_bf16_f32, round to
-// nearest even); the rounded values come back as fp32 by a shift / a mask of the packed words (left to the compiler the round trip
-// was four more single conversions per level: 14 conversions per call instead of 6)
+// four fp32 -> three planes of four bf16 (two words per plane), round to nearest even at every level.  hipcc turns the vector
+// conversions into two v_cvt_pk_bf16_f32 per level for the planes PLUS four single conversions for the round trip back to fp32 (14
+// conversions per call).  A hand-written form that reuses the packed words (shift / mask: 22 VALU instead of 38, -13 % VALU
+// instructions in the SQ counters) measured EQUAL in the conv kernel and 8-11 % SLOWER in the weight-gradient kernel
+// (profiles/r05_experiments.md section 8): kept behind DR_X3_SPLIT_HAND for the record, not built.
 typedef float dr_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 dr_bf16x2 __attribute__((ext_vector_type(2)));
 __host__ __device__ static inline unsigned x3_pack2(float a, float b) {
@@ -34,12 +36,22 @@ __host__ __device__ static inline unsigned x3_pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f, dr_bf16x2));
 }
 __host__ __device__ static inline void x3_split4(const float4 v, uint2& h0, uint2& h1, uint2& h2) {
+#if !defined(DR_X3_SPLIT_HAND)
+    const dr_f32x4 f = {v.x, v.y, v.z, v.w};
+    const dr_bf16x4 b0 = __builtin_convertvector(f, dr_bf16x4);
+    const dr_f32x4 q1 = f - __builtin_convertvector(b0, dr_f32x4);
+    const dr_bf16x4 b1 = __builtin_convertvector(q1, dr_bf16x4);
+    const dr_f32x4 q2 = q1 - __builtin_convertvector(b1, dr_f32x4);
+    const dr_bf16x4 b2 = __builtin_convertvector(q2, dr_bf16x4);
+    h0 = __builtin_bit_cast(uint2, b0); h1 = __builtin_bit_cast(uint2, b1); h2 = __builtin_bit_cast(uint2, b2);
+#else
     auto lo = [](unsigned w) { return __builtin_bit_cast(float, w << 16); };
     auto hi = [](unsigned w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); };
     h0 = make_uint2(x3_pack2(v.x, v.y), x3_pack2(v.z, v.w));
     const float r0 = v.x - lo(h0.x), r1 = v.y - hi(h0.x), r2 = v.z - lo(h0.y), r3 = v.w - hi(h0.y);
     h1 = make_uint2(x3_pack2(r0, r1), x3_pack2(r2, r3));
     h2 = make_uint2(x3_pack2(r0 - lo(h1.x), r1 - hi(h1.x)), x3_pack2(r2 - lo(h1.y), r3 - hi(h1.y)));
+#endif
 }
 
 // RING = 1: three LDS stages instead of two.  With two, a K-tile ends "ds_write the next tile, barrier, ds_read the fragments, wait":
@@ -347,7 +359,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
     constexpr int EP_TM = kTM, EP_TN = kTN;
     const int ep_m0 = m0 + wm * kWTM, ep_n0 = n0 + wn * kWTN;
     const unsigned ep_rows = 0xFFFFu;
-    constexpr int EP_BATCH_ROWS = NW == 8 ? 4 : 8;          // (eight waves live on 128 registers: four rows of epilogue loads in flight)
+#if !defined(DR_X3_EPB)
+#define DR_X3_EPB 4                                          // (A/B builds: 8)
+#endif
+    constexpr int EP_BATCH_ROWS = NW == 8 ? DR_X3_EPB : 8;  // (eight waves live on 128 registers: four rows of epilogue loads in flight)
     constexpr int EP_TS = MF, EP_NR = NR;
     const int ep_lg = lk, ep_lc = li;
     {

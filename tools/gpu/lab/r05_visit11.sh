@@ -21,3 +21,7 @@ SHAPE="32 78 78 3 -1 3" probe igemm16_3x3_78 conv_igemm DR_X3_BN96=0
 SHAPE="32 256 156 1 -1 3" probe igemm16_1x1_256_156 conv_igemm A=1
 SHAPE="32 78 78 3 -1 3" probe x3_96_3x3_78 conv_x3 A=1
 head -30 gpurun_out/v11_counters_igemm16_3x3_78.md; head -12 gpurun_out/v11_counters_igemm16_1x1_256_156.md; head -12 gpurun_out/v11_counters_x3_96_3x3_78.md
+# the whole GPU suite with the x3 kernels forced onto EVERY layer they can run (DR_CONV_X3=2: shallow grids, 16x16 and below, K < 128 too)
+cd $R; rm -f gpurun_out/pytest_live.log
+( time DR_CONV_X3=2 timeout 1100 python -m pytest tests/ -q -m gpu -p no:cacheprovider ) > gpurun_out/v11_suite_x3_everywhere.log 2>&1; echo "rc=$?" >> gpurun_out/v11_suite_x3_everywhere.log
+grep -v "start\]\|passed\]" gpurun_out/v11_suite_x3_everywhere.log | tail -15

@@ -129,6 +129,12 @@ class EmuBackend(Backend):
         from tests.emu import load_emu
         self.lib = load_emu()
         self.dbg = self.lib                 # the emulator build carries the dr_dbg_* hooks itself
+        # The emulator runs the fp32-MFMA kernels unless a test asks for the x3 ones (dr_dbg_force_x3): a fiber-emulated bf16 MFMA with
+        # LDS transpose reads is several times slower than the emulated fp32 MFMA, and with the x3 weight gradients on by default the
+        # CPU suite took 16 minutes instead of 10.  The x3 kernels keep their own emulator tests (test_conv_x3_..., test_wgrad_x3_...);
+        # at network level they are covered on the GPU (by default and, once per round, on every layer: DR_CONV_X3=2).
+        self.x3_default = 0
+        self.dbg.dr_dbg_force_x3(self.x3_default)
 
     def dev(self, a):
         return np.ascontiguousarray(a).copy()
@@ -145,6 +151,7 @@ class EmuBackend(Backend):
 
 class GpuBackend(Backend):
     name = 'gpu'
+    x3_default = -1                         # the product's rule (DR_CONV_X3 / DR_WGRAD_X3)
 
     def __init__(self):
         import torch

@@ -111,7 +111,7 @@ def test_conv_x3_fp32_accurate_products_on_the_bf16_matrix_cores(be, case):
             assert be.dbg.dr_dbg_force_x3(mode) == 0
             outs[mode] = be.conv2d(x, w, scale, shift, True, res, mask, -0.5, want_stats=True)
         finally:
-            be.dbg.dr_dbg_force_x3(-1)
+            be.dbg.dr_dbg_force_x3(be.x3_default)
     e32, e3 = _rel(outs[0][0], yr), _rel(outs[2][0], yr)
     rms = lambda y: float(np.sqrt(np.mean((y - yr) ** 2)) / (np.abs(yr).max() + 1e-12))
     r32, r3 = rms(outs[0][0]), rms(outs[2][0])

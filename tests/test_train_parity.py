@@ -645,7 +645,7 @@ def test_wgrad_x3_against_the_fp32_matrix_cores(be, case):
             assert be.dbg.dr_dbg_force_x3(mode) == 0
             dw = be.wgrad(x, g, k, T, nsplit, mask, -0.25)
         finally:
-            be.dbg.dr_dbg_force_x3(-1)
+            be.dbg.dr_dbg_force_x3(be.x3_default)
         err[mode] = np.abs(dw - ref).max() / np.abs(ref).max()
     assert err[2] < 2e-5 and err[0] < 2e-5, err
     assert err[2] < 6 * err[0] + 2e-7, err

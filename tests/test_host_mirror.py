@@ -148,6 +148,38 @@ def test_synthetic_dataset_constants():
     assert 0.25 < (dm > 0).mean() < 0.6 and np.all(cfg[:, 4:] == 128)
 
 
+def test_learnable_synthetic_hands_are_a_function_of_the_image():
+    """``make_hand_crops`` (the crops the engine trains itself on, tests/test_trained_parity.py): seeded and reproducible, every joint
+    projects onto the hand it belongs to (the palm centre and points along the five fingers, 6 mm behind the visible surface), the
+    centre of mass follows data/preprocess.py:131-142, and -- unlike ``make_crops`` -- two crops with the same geometry give the
+    same joints (the joints are not random foreground pixels)."""
+    from densereg_amd.data.synthetic import DATASETS, center_of_mass, make_hand_crops
+    for dataset in ('icvl', 'nyu', 'msra'):
+        J = DATASETS[dataset]['jnt_num']
+        dm, pose, cfg, com, names = make_hand_crops(6, dataset, seed=3)
+        dm2, pose2, cfg2, com2, _ = make_hand_crops(6, dataset, seed=3)
+        np.testing.assert_array_equal(dm, dm2)
+        np.testing.assert_array_equal(pose, pose2)
+        assert dm.shape == (6, 128, 128, 1) and pose.shape == (6, 3 * J) and len(names) == 6
+        other = make_hand_crops(6, dataset, seed=4)[1]
+        assert np.abs(other - pose).max() > 1.0                        # another seed, another hand
+        for b in range(6):
+            img, j = dm[b, :, :, 0], pose[b].reshape(J, 3)
+            fg = img > 0
+            assert 0.08 < fg.mean() < 0.35
+            np.testing.assert_allclose(com[b], center_of_mass(img, cfg[b]), rtol=1e-6)
+            u = j[:, 0] * cfg[b, 0] / j[:, 2] + cfg[b, 2]
+            v = j[:, 1] * cfg[b, 1] / j[:, 2] + cfg[b, 3]
+            iu, iv = np.clip(np.round(u).astype(int), 0, 127), np.clip(np.round(v).astype(int), 0, 127)
+            assert fg[iv, iu].all(), (dataset, b)                      # every joint lies on the silhouette ...
+            np.testing.assert_allclose(j[:, 2], img[iv, iu] + 6.0, atol=1e-3)      # ... 6 mm behind the surface the camera sees
+            # fingers fan out from the palm: the joints of one finger (j = 1 + f + 5 s) move away from the palm centre with s
+            d = np.hypot(u - u[0], v - v[0])
+            for f in range(5):
+                chain = d[1 + f::5]
+                assert (np.diff(chain) > 0).all(), (dataset, b, f)
+
+
 def test_accumulation_window_as_one_pass_policy_and_bookkeeping():
     """parallel.window_groups picks the pass size; DataParallelTrainer.window_step does the bookkeeping of `sub_batch` micro-steps
     and the optimizer step around ONE forward / loss / backward of the engine in groups mode."""

@@ -80,6 +80,10 @@ struct ConvParams {
     // conv_x3.h: the same weights as three bf16 planes [Kp/16][tap][3][Np][16] (w = w0 + w1 + w2 to fp32 accuracy), or null.  With
     // it the launcher may run the layer on the bf16 matrix cores with fp32-accurate products (launch_conv_igemm: conv_use_x3).
     const void* w3;
+    // conv_p3.h: the input STORED as its three bf16 planes ("P3": [M][xp3_cp/16][3][16] bf16, xp3_cp = Cin rounded up to 16, pad
+    // channels zero; the whole tensor: no channel offset), or null.  With it (and w3) the launcher runs conv_p3_kernel where its tile
+    // applies: the same products as conv_x3_kernel without the operand split in the K loop.  x stays valid or null (p.xp3 wins).
+    const void* xp3; int xp3_cp;
 };
 
 // stateless keep bit for dropout(0.5): splitmix64 finaliser of (seed, element index)

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
         a_taps[i] = ok ? mask : 0u;
         a_off[i] = ok ? (unsigned)((long)m * p.x_cs + p.x_coff + a_q[i] * 4) : 0u;
     }
-    // weight planes: unit u = (plane, row, slot), 16 bytes = 8 bf16; the three planes of a K-tile are Np * 16 bf16 apart
+    // weight planes: unit u = (plane, row, slot), 16 bytes = 8 bf16; the three planes of a row are 16 bf16 apart
     const __bf16* const w3 = reinterpret_cast<const __bf16*>(p.w3);
     unsigned b_off[kBIters]; int b_lds[kBIters]; bool b_ok[kBIters];
 #pragma unroll
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
         const int u = tid + i * NT;
         const int pl = u / (BN * 2), within = u % (BN * 2), row = within >> 1, slot = within & 1;
         b_ok[i] = u < kBUnits && n0 + row < p.Np;
-        b_off[i] = (unsigned)((pl * p.Np + n0 + row) * 16 + slot * 8);
+        b_off[i] = (unsigned)(((n0 + row) * 3 + pl) * 16 + slot * 8);
         b_lds[i] = (pl * BN + row) * 2 + (slot ^ ((row >> 3) & 1));
     }
     const long w_tile = 3l * p.Np * 16;                                    // bf16 elements per (chunk, tap)
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
         const int L = (wave + NW * i) * 64 + lane;
         const int pl = L / (BN * 2), within = L % (BN * 2), row = within >> 1, slot = (within & 1) ^ ((row >> 3) & 1);
         bd_ok[i] = L < kBUnits && n0 + row < p.Np;
-        bd_off[i] = (unsigned)((pl * p.Np + n0 + row) * 16 + slot * 8);
+        bd_off[i] = (unsigned)(((n0 + row) * 3 + pl) * 16 + slot * 8);
     }
     const __bf16* dma_w = w3;
     auto dma_b = [&](const int st) __attribute__((always_inline)) {

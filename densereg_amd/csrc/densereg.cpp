@@ -9,6 +9,7 @@
 #include "conv_igemm.h"
 #include "conv_splitk.h"
 #include "conv_x3.h"
+#include "conv_p3.h"
 #include "conv_wgrad.h"
 #include "conv_wgrad_bf16.h"
 #include "conv_wgrad_tr.h"
@@ -89,21 +90,24 @@ static bool conv_use_glds(const ConvParams& p) {
     return on && p.Cin % 4 == 0;
 }
 
+static long g_p3_launches = 0;       // conv_p3.h launches of this process (test hook dr_dbg_p3_launches: "the kernel under test is the one that ran")
 static int g_force_tile = -1;        // test/bench hook (dr_dbg_conv_bench); -1 = heuristic
 static int g_dbg_bf16 = 0;           // test/bench hook (dr_dbg_force_bf16): dr_dbg_conv2d / dr_dbg_conv_bench run the bf16 kernels
 static int g_dbg_bf16_storage = 0;   // test hook (dr_dbg_force_bf16_storage): bf16-stored x / g / draw in the debug entries
 
 static int conv_tile_heuristic(const ConvParams& p);
 bool conv_use_x3(const ConvParams& p);
+bool conv_use_p3(const ConvParams& p);
 static int tile_rows_of(int t) {
     if (t == KID_CONV_SPLITK) return 32;
-    if (t == KID_CONV_X3) return 128;
+    if (t == KID_CONV_X3 || t == KID_CONV_P3) return 128;
     return (t == KID_CONV_64x128 || t == KID_CONV_64x64 || t == KID_CONV_64x64_K64 || t == KID_CONV_64x96 || t == KID_CONV_64x160 ||
             (t >= KID_CONV16_64x80 && t <= KID_CONV16_64x160)) ? 64 : 128;
 }
 // tile shape for a problem (shared by the launcher and the profiler labels)
 int conv_tile_id(const ConvParams& p) {
     if (g_force_tile >= 0) return g_force_tile;
+    if (conv_use_p3(p)) return KID_CONV_P3;
     if (conv_use_x3(p)) return KID_CONV_X3;
     const int t = conv_tile_heuristic(p);
     // micro-batch groups: a workgroup's rows must lie in one group (per-group statistics rows, per-group coefficients) -- where
@@ -167,6 +171,7 @@ bool conv_use_x3(const ConvParams& p) {
     static const int env = [] { const char* e = getenv("DR_CONV_X3"); return e ? atoi(e) : 1; }();
     const int mode = g_dbg_x3 >= 0 ? g_dbg_x3 : env;
     if (mode <= 0 || !p.w3 || p.bf16 || p.x_bf16 || p.y_bf16 || p.bst_raw_bf16 || g_force_tile >= 0) return false;
+    if (!p.x && !p.xp3) return false;
     if (p.grp_rows > 0 && p.grp_rows % 128 != 0) return false;
     if (mode >= 2) return true;
     const long M = (long)p.B * p.H * p.W;
@@ -184,6 +189,17 @@ bool conv_use_x3(const ConvParams& p) {
     return bn64 && ncols % 64 == 0 && dr_ceil_div((int)M, 128) * (long)(ncols / 64) >= 2 * min_wgs && (long)p.ksize * p.ksize * p.Kp >= 128;
 }
 
+// conv_p3.h (the x3 products on an input stored as its three bf16 planes): what the kernel can run -- whole 128-column blocks, at
+// least two K-tiles, the whole P3 tensor as input.  conv_p3_applies: the SHAPE rule alone, for the producer that must decide how
+// to store the tensor before the consumer's launch exists (train_exec.inc); conv_use_p3: + "the input is there".
+bool conv_p3_applies(const ConvParams& p) {
+    if (!conv_use_x3(p)) return false;
+    const int ncols = p.Ng > 0 ? p.Ng : p.Np;
+    static const bool on = [] { const char* e = getenv("DR_CONV_P3"); return !(e && e[0] == '0'); }();
+    return on && ncols % 128 == 0 && p.ksize * p.ksize * (p.Kp / 16) >= 2 && p.x_coff == 0;
+}
+bool conv_use_p3(const ConvParams& p) { return p.xp3 && p.xp3_cp == p.Kp && conv_p3_applies(p); }
+
 // output rows per workgroup of the tile a problem gets
 int conv_tile_rows(const ConvParams& p) { return tile_rows_of(conv_tile_id(p)); }
 // rows of ConvParams::stat_part the launch writes = workgroups along M of the chosen tile
@@ -200,6 +216,29 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     if (p.y_bf16 && !p.bst_raw_bf16 && (p.scale || p.shift || p.relu || p.res || p.drop || p.drop_rng || p.bst_raw || p.out_rowmask)) return -1;
     if (p.y_bf16 && p.bst_raw_bf16 && p.res) return -1;                  // a bf16-stored dOut has ONE writer
     if (p.bst_raw_bf16 && (!p.bst_raw || p.bst_act || p.scale || p.shift || p.relu || p.drop || p.drop_rng)) return -1;
+    if (conv_tile_id(p) == KID_CONV_P3) {
+        static const int nfast = [] { const char* e = getenv("DR_CONV_NFAST"); return (e && e[0] == '0') ? 0 : 1; }();
+        if (M * (long long)p.xp3_cp * 6 + 2ll * (p.W + 1) * p.xp3_cp * 6 >= (1ll << 31)) return -1;   // 31-bit byte offsets into the P3 tensor
+        ConvParams q = p;
+        q.nfast = nfast;
+        const int ncols = p.Ng > 0 ? p.Ng : p.Np;
+        dim3 grid(dr_ceil_div((int)M, 128), ncols / 128);
+        q.gx = (int)grid.x; q.gy = (int)grid.y;
+#if defined(DR_DEBUG_HOOKS)
+        static const int var = [] { const char* e = getenv("DR_P3_VARIANT"); return e ? atoi(e) : 0; }();
+        switch (var) {
+            case 1: DR_LAUNCH((conv_p3_kernel<128, 1>), grid, dim3(512), 0, s, q); break;
+            case 2: DR_LAUNCH((conv_p3_kernel<128, 2>), grid, dim3(512), 0, s, q); break;
+            case 4: DR_LAUNCH((conv_p3_kernel<128, 4>), grid, dim3(512), 0, s, q); break;
+            case 6: DR_LAUNCH((conv_p3_kernel<128, 6>), grid, dim3(512), 0, s, q); break;
+            default: DR_LAUNCH((conv_p3_kernel<128>), grid, dim3(512), 0, s, q); break;
+        }
+#else
+        DR_LAUNCH((conv_p3_kernel<128>), grid, dim3(512), 0, s, q);
+#endif
+        ++g_p3_launches;
+        return 0;
+    }
     if (conv_tile_id(p) == KID_CONV_X3) {
         static const int nfast = [] { const char* e = getenv("DR_CONV_NFAST"); return (e && e[0] == '0') ? 0 : 1; }();
         static const int variant = [] { const char* e = getenv("DR_X3_VARIANT"); return e ? atoi(e) : 0; }();
@@ -357,15 +396,15 @@ __global__ __launch_bounds__(256) void pack_weights_T_kernel(const float* w, flo
 // Every layer's forward and dgrad packing in ONE launch (292 separate ~3 us launches per optimizer step otherwise).
 // Segment s covers workgroups [first_block, next first_block) of 256 packed elements each.
 struct PackSeg { long w_off; long dst_off; int taps, Cin, Cout, Kp, Np, transposed, first_block; };
-// conv_x3.h: element i of an fp32 packed buffer [chunk][tap][Np][16] as three bf16 planes [chunk][tap][3][Np][16]
+// conv_x3.h / conv_p3.h: element i of an fp32 packed buffer [chunk][tap][Np][16] as three bf16 planes [chunk][tap][Np][3][16]
 __device__ __forceinline__ void x3_store_planes(__bf16* w3, long i, int Np, float v) {
-    const long tile = (long)Np * 16, b = i / tile, within = i % tile;
+    (void)Np;
     const __bf16 h0 = (__bf16)v;
     const float r1 = v - (float)h0;
     const __bf16 h1 = (__bf16)r1;
     const __bf16 h2 = (__bf16)(r1 - (float)h1);
-    __bf16* d = w3 + (b * 3) * tile + within;
-    d[0] = h0; d[tile] = h1; d[2 * tile] = h2;
+    __bf16* d = w3 + (i >> 4) * 48 + (i & 15);
+    d[0] = h0; d[16] = h1; d[32] = h2;
 }
 // a whole fp32 packed buffer -> planes (debug entry points; the handle's weights go through pack_all_kernel)
 __global__ __launch_bounds__(256) void pack_x3_kernel(const float* wp, __bf16* w3, long total, int Np) {

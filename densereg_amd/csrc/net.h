@@ -118,6 +118,7 @@ enum KernelId {
     KID_WGRAD_128, KID_WGRAD_64, KID_WGRAD_ROW, KID_WGRAD_GROUP, KID_WGRAD_16,   // one row per weight-gradient kernel template (KID_WGRAD: the stem's)
     KID_CONV_X3,                     // conv_x3.h (named conv_x3_128x128: bench.py prices it against the bf16 matrix cores / 6)
     KID_WGRAD_X3_128, KID_WGRAD_X3_64,   // conv_wgrad_x3.h
+    KID_CONV_P3,                     // conv_p3.h (the x3 products on a P3-stored input; priced like conv_x3_128x128)
     KID_COUNT
 };
 static const char* const kKernelNames[KID_COUNT] = {
@@ -125,7 +126,7 @@ static const char* const kKernelNames[KID_COUNT] = {
     "conv_igemm_64x96", "conv_igemm_64x160", "conv_igemm16_64x80", "conv_igemm16_64x144", "conv_igemm16_64x160",
     "stem_conv", "maxpool",
     "upsample_add", "uvd", "copy_channels", "hourglass_tail_fused", "vote", "batch_renorm", "stem_wgrad", "wgrad_fold", "eltwise_bwd", "loss", "adam",
-    "conv_wgrad_128", "conv_wgrad_64", "conv_wgrad_row96", "conv_wgrad_group", "conv_wgrad16", "conv_x3_128x128", "conv_wgrad_x3_128", "conv_wgrad_x3_64"};
+    "conv_wgrad_128", "conv_wgrad_64", "conv_wgrad_row96", "conv_wgrad_group", "conv_wgrad16", "conv_x3_128x128", "conv_wgrad_x3_128", "conv_wgrad_x3_64", "conv_p3_128x128"};
 
 // The part of one hourglass below 16x16 pixels (hg_fused.h): in eval mode the ops [first_op, last_op] and the pool at pool_op are
 // ONE launch.  conv[]: the ConvLayer indices of its eight residual modules in execution order.

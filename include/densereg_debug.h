@@ -97,6 +97,10 @@ int dr_dbg_force_bf16_storage(int on);
 /* conv_x3.h (fp32-accurate products on the bf16 matrix cores): -1 = DR_CONV_X3 / the measured rule, 0 = never, 1 = the rule, 2 = wherever
  * the kernel can run -- for the debug entries and every handle of the process */
 int dr_dbg_force_x3(int mode);
+/* ... 3 / 4 / 5: as 2 with one accumulator / the three-stage LDS ring / four waves per workgroup; 6: as 2, and the debug entries store the
+ * input of a convolution as its three bf16 planes ("P3", densereg_amd/csrc/conv_p3.h) so that conv_p3_kernel runs where its tile applies.
+ * dr_dbg_p3_launches: conv_p3_kernel launches of this process so far (a test's proof that the kernel under test is the one that ran). */
+long dr_dbg_p3_launches(void);
 
 /* Partial statistics rows one wave of a BatchReNorm finalize launch folds before the micro-batch group gets another wave
  * (densereg_amd/csrc/train_kernels.h: bn_finalize_split; default 512, 0 restores it).  Process-global; tests lower it so that

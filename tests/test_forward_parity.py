@@ -87,6 +87,9 @@ def test_conv_splitk_kernel_fused_epilogue(be, case, tile):
 X3_CASES = CONV_CASES + [
     # (B, H, W, Cin, Cout, k): more than one 128-row / 128-column block, ragged rows, K tails of 1..3 channels, Cout beyond a block
     (2, 12, 11, 64, 128, 3), (1, 16, 16, 256, 256, 1), (3, 7, 7, 33, 130, 3), (1, 20, 13, 515, 200, 1), (2, 8, 8, 18, 40, 3),
+    # whole 128-column blocks: what conv_p3.h takes (mode 6) -- ragged Cin (chunks of 16 with zero pads), masked rows, ragged last row
+    # block, two column blocks, two K-tiles only (the shortest ring), a K-tile count of every residue mod 3
+    (1, 9, 10, 40, 128, 3), (2, 7, 9, 131, 256, 1), (1, 16, 8, 32, 128, 1), (1, 11, 12, 78, 128, 3), (1, 13, 10, 64, 128, 1),
 ]
 
 
@@ -106,10 +109,13 @@ def test_conv_x3_fp32_accurate_products_on_the_bf16_matrix_cores(be, case):
     mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if k == 1 else None
     yr, raw = ref_conv2d(x, w, scale, shift, True, res, mask, -0.5)
     outs = {}
-    for mode in (0, 2, 4, 5):                                # fp32 matrix cores | x3 (default: eight waves) | three-stage LDS ring | four waves
+    for mode in (0, 2, 4, 5, 6):                             # fp32 matrix cores | x3 (default: eight waves) | three-stage LDS ring | four waves | P3-stored input
         try:
             assert be.dbg.dr_dbg_force_x3(mode) == 0
+            n_p3 = be.dbg.dr_dbg_p3_launches()
             outs[mode] = be.conv2d(x, w, scale, shift, True, res, mask, -0.5, want_stats=True)
+            # (whole 128-column blocks and at least two K-tiles: conv_p3_kernel itself must have run in mode 6, and only there)
+            assert be.dbg.dr_dbg_p3_launches() - n_p3 == (1 if mode == 6 and (-(-Cout // 32) * 32) % 128 == 0 and k * k * -(-Cin // 16) >= 2 else 0)
         finally:
             be.dbg.dr_dbg_force_x3(be.x3_default)
     e32, e3 = _rel(outs[0][0], yr), _rel(outs[2][0], yr)
@@ -123,6 +129,9 @@ def test_conv_x3_fp32_accurate_products_on_the_bf16_matrix_cores(be, case):
     # every variant multiplies the same planes in the same K order: the same bits, whatever the staging and the wave layout
     np.testing.assert_array_equal(outs[2][0], outs[4][0])
     np.testing.assert_array_equal(outs[2][0], outs[5][0])
+    # conv_p3.h: the input split ONCE by p3_split_kernel, both tiles by LDS-DMA -- the same planes, the same product order
+    np.testing.assert_array_equal(outs[2][0], outs[6][0])
+    np.testing.assert_array_equal(outs[2][1], outs[6][1])
     for y, st in outs.values():
         np.testing.assert_allclose(st[0], raw.sum((0, 1, 2)), rtol=1e-4, atol=1e-4 * float(np.abs(raw).max()) * raw[..., 0].size ** 0.5)
         np.testing.assert_allclose(st[1], (raw ** 2).sum((0, 1, 2)), rtol=1e-4)

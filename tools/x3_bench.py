@@ -21,19 +21,20 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     dbg = _lib.load_debug()
     ms = C.c_float()
-    print('| shape (HxW, Cin->Cout, k) at %d crops | fp32 MFMA us | TFLOP/s | x3 us | TFLOP/s | x3 four waves us | TFLOP/s | x3 ring us | TFLOP/s | x3 / fp32 |' % B)
-    print('|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|')
+    print('| shape (HxW, Cin->Cout, k) at %d crops | fp32 MFMA us | TFLOP/s | x3 us | TFLOP/s | x3 four waves us | TFLOP/s | x3 ring us | TFLOP/s | p3 us | TFLOP/s | x3 / fp32 | p3 / x3 |' % B)
+    print('|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|')
     for hw, cin, cout, k in SHAPES:
         fl = 2.0 * B * hw * hw * k * k * cin * cout
         row = []
-        for mode in (0, 2, 5, 4):
+        for mode in (0, 2, 5, 4, 6):
             dbg.dr_dbg_force_x3(mode)
             rc = dbg.dr_dbg_conv_bench(B, hw, hw, cin, cout, k, -1, 0, 10, C.byref(ms))
             assert rc == 0, rc
             row.append(ms.value * 1e3)
         dbg.dr_dbg_force_x3(-1)
-        print('| %dx%d %d->%d k%d | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.2fx |' % (
-            hw, hw, cin, cout, k, row[0], fl / row[0] / 1e6, row[1], fl / row[1] / 1e6, row[2], fl / row[2] / 1e6, row[3], fl / row[3] / 1e6, row[0] / row[1]))
+        print('| %dx%d %d->%d k%d | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.2fx | %.2fx |' % (
+            hw, hw, cin, cout, k, row[0], fl / row[0] / 1e6, row[1], fl / row[1] / 1e6, row[2], fl / row[2] / 1e6, row[3], fl / row[3] / 1e6,
+            row[4], fl / row[4] / 1e6, row[0] / row[1], row[1] / row[4]))
         sys.stdout.flush()
     # errors against fp64 on one big layer (network-like operands: post-ReLU activations, He weights)
     from tests.common import GpuBackend, ref_conv2d

@@ -104,6 +104,7 @@ DEBUG_SIGNATURES = {
     'dr_dbg_force_bf16_storage': (_i, [_i]),
     'dr_dbg_force_x3': (_i, [_i]),
     'dr_dbg_p3_launches': (C.c_long, []),
+    'dr_dbg_x3h_launches': (C.c_long, []),
     'dr_dbg_bn_finalize_rows': (_i, [_i]),
     'dr_dbg_wgrad_bench': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(_i)]),
     'dr_dbg_bn_bench': (_i, [C.c_long, _i, _i, _i, C.POINTER(C.c_float)]),

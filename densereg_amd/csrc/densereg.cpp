@@ -10,6 +10,7 @@
 #include "conv_splitk.h"
 #include "conv_x3.h"
 #include "conv_p3.h"
+#include "conv_x3h.h"
 #include "conv_wgrad.h"
 #include "conv_wgrad_bf16.h"
 #include "conv_wgrad_tr.h"
@@ -90,6 +91,7 @@ static bool conv_use_glds(const ConvParams& p) {
     return on && p.Cin % 4 == 0;
 }
 
+static long g_x3h_launches = 0;      // conv_x3h.h launches of this process (dr_dbg_x3h_launches)
 static long g_p3_launches = 0;       // conv_p3.h launches of this process (test hook dr_dbg_p3_launches: "the kernel under test is the one that ran")
 static int g_force_tile = -1;        // test/bench hook (dr_dbg_conv_bench); -1 = heuristic
 static int g_dbg_bf16 = 0;           // test/bench hook (dr_dbg_force_bf16): dr_dbg_conv2d / dr_dbg_conv_bench run the bf16 kernels
@@ -258,6 +260,16 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         const bool ring = false;
 #endif
         const bool w4 = (variant & 4) || g_dbg_x3 == 5 || one_acc || ring;
+        // conv_x3h.h: 3x3 layers whose 128-row tiles are whole image rows keep the haloed input tile in LDS across the nine taps
+        // (DR_X3_HALO=0 / dr_dbg_force_x3(7): conv_x3_kernel everywhere)
+        static const bool halo_on = [] { const char* e = getenv("DR_X3_HALO"); return !(e && e[0] == '0'); }();
+        if (halo_on && g_dbg_x3 != 7 && p.ksize == 3 && !bn96 && !bn64 && !one_acc && !ring && !w4 && !p.rowmask && (p.W == 32 || p.W == 16) &&
+            (p.H * p.W) % 128 == 0) {
+            if (p.W == 32) DR_LAUNCH((conv_x3h_kernel<128, 5>), grid, dim3(512), 0, s, q);
+            else DR_LAUNCH((conv_x3h_kernel<128, 4>), grid, dim3(512), 0, s, q);
+            ++g_x3h_launches;
+            return 0;
+        }
         if (bn96) {
             DR_LAUNCH((conv_x3_kernel<128, 96, 1, 0, 4, 4>), grid, dim3(256), 0, s, q);
         } else if (bn64) {

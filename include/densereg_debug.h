@@ -101,6 +101,9 @@ int dr_dbg_force_x3(int mode);
  * input of a convolution as its three bf16 planes ("P3", densereg_amd/csrc/conv_p3.h) so that conv_p3_kernel runs where its tile applies.
  * dr_dbg_p3_launches: conv_p3_kernel launches of this process so far (a test's proof that the kernel under test is the one that ran). */
 long dr_dbg_p3_launches(void);
+/* ... 7: as 2, but conv_x3_kernel also where conv_x3h_kernel (densereg_amd/csrc/conv_x3h.h: 3x3 layers with the haloed input tile resident in
+ * LDS across the nine taps) would run.  dr_dbg_x3h_launches: conv_x3h_kernel launches of this process so far. */
+long dr_dbg_x3h_launches(void);
 
 /* Partial statistics rows one wave of a BatchReNorm finalize launch folds before the micro-batch group gets another wave
  * (densereg_amd/csrc/train_kernels.h: bn_finalize_split; default 512, 0 restores it).  Process-global; tests lower it so that

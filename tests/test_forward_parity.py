@@ -90,6 +90,9 @@ X3_CASES = CONV_CASES + [
     # whole 128-column blocks: what conv_p3.h takes (mode 6) -- ragged Cin (chunks of 16 with zero pads), masked rows, ragged last row
     # block, two column blocks, two K-tiles only (the shortest ring), a K-tile count of every residue mod 3
     (1, 9, 10, 40, 128, 3), (2, 7, 9, 131, 256, 1), (1, 16, 8, 32, 128, 1), (1, 11, 12, 78, 128, 3), (1, 13, 10, 64, 128, 1),
+    # 3x3 on 16- / 32-pixel-wide images whose 128-row tiles are whole image rows: what conv_x3h.h takes (the haloed tile resident in LDS) --
+    # one tile per image (every halo row outside), several tiles per image (halo rows from the neighbours), ragged Cin, one chunk only
+    (1, 8, 16, 40, 128, 3), (2, 4, 32, 24, 128, 3), (2, 8, 32, 35, 256, 3), (1, 16, 16, 64, 128, 3), (3, 12, 32, 16, 128, 3),
 ]
 
 
@@ -109,11 +112,13 @@ def test_conv_x3_fp32_accurate_products_on_the_bf16_matrix_cores(be, case):
     mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if k == 1 else None
     yr, raw = ref_conv2d(x, w, scale, shift, True, res, mask, -0.5)
     outs = {}
-    for mode in (0, 2, 4, 5, 6):                             # fp32 matrix cores | x3 (default: eight waves) | three-stage LDS ring | four waves | P3-stored input
+    halo = k == 3 and W in (16, 32) and (H * W) % 128 == 0 and (-(-Cout // 32) * 32) % 128 == 0      # conv_x3h.h takes the layer in modes 2 and 6 (no P3 input there: rule order)
+    for mode in (0, 2, 4, 5, 6, 7):                          # fp32 matrix cores | x3 (default: eight waves, halo kernel where it applies) | three-stage LDS ring | four waves | P3-stored input | no halo kernel
         try:
             assert be.dbg.dr_dbg_force_x3(mode) == 0
-            n_p3 = be.dbg.dr_dbg_p3_launches()
+            n_p3, n_h = be.dbg.dr_dbg_p3_launches(), be.dbg.dr_dbg_x3h_launches()
             outs[mode] = be.conv2d(x, w, scale, shift, True, res, mask, -0.5, want_stats=True)
+            assert be.dbg.dr_dbg_x3h_launches() - n_h == (1 if mode == 2 and halo else 0)
             # (whole 128-column blocks and at least two K-tiles: conv_p3_kernel itself must have run in mode 6, and only there)
             assert be.dbg.dr_dbg_p3_launches() - n_p3 == (1 if mode == 6 and (-(-Cout // 32) * 32) % 128 == 0 and k * k * -(-Cin // 16) >= 2 else 0)
         finally:
@@ -129,6 +134,9 @@ def test_conv_x3_fp32_accurate_products_on_the_bf16_matrix_cores(be, case):
     # every variant multiplies the same planes in the same K order: the same bits, whatever the staging and the wave layout
     np.testing.assert_array_equal(outs[2][0], outs[4][0])
     np.testing.assert_array_equal(outs[2][0], outs[5][0])
+    # conv_x3h.h (mode 2 where it applies) against conv_x3_kernel on the same layer (mode 7): the same planes, the same product order
+    np.testing.assert_array_equal(outs[2][0], outs[7][0])
+    np.testing.assert_array_equal(outs[2][1], outs[7][1])
     # conv_p3.h: the input split ONCE by p3_split_kernel, both tiles by LDS-DMA -- the same planes, the same product order
     np.testing.assert_array_equal(outs[2][0], outs[6][0])
     np.testing.assert_array_equal(outs[2][1], outs[6][1])

@@ -6,7 +6,7 @@
 // LDS again -- 9 x the loads, the ~40-instruction split and the ds_writes (profiles/r05_conv_x3_sq_counters.md: 6.7 VALU instructions
 // per MFMA).  Here a workgroup's 128 output pixels are whole image rows (W divides 128), so the pixels its nine taps read are ONE
 // haloed tile of (128 / W + 2) x (W + 2) pixels: per 16-channel chunk it is fetched, split and stored once (1.6 float4 units per
-// thread at W = 32 instead of 9; one unit at a time through one staging register: fetched in tap 1 / 3 / 5, stored two taps later) and the nine taps read their A fragments from it at a shifted row -- the shift is address
+// thread at W = 32 instead of 9; one unit at a time through one staging register: fetched in tap 0 / 2 / 4 / 6, stored two taps later) and the nine taps read their A fragments from it at a shifted row -- the shift is address
 // arithmetic on the fragment read (five VALU instructions per 32-row group and tap), TF's 'SAME' zero padding is zeros stored in the
 // halo.  The weight tile of every tap (pre-split planes, conv_x3.h) goes L2 -> LDS by LDS-DMA (conv_p3.h: inline asm with counted waits,
 // two stages): no staging registers -- with them hipcc, at the 128-register limit of four waves per SIMD, sank each weight load to
@@ -22,12 +22,14 @@
 
 namespace dr {
 
-// LW = log2(image width): 5 (the 32x32 maps of every configuration at 128x128 input) or 4
-template <int BN, int LW>
-__global__ __launch_bounds__(512, 4) void conv_x3h_kernel(const ConvParams p) {
-    constexpr int BM = 128, NT = 512, NW = 8, WM = 2, WN = 4, MF = 32, ABL = 0, CK = 16;
+// LW = log2(image width): 5 (the 32x32 maps of every configuration at 128x128 input) or 4.  Tiles as conv_x3_kernel's: 128 columns = eight
+// waves of 64x32 (NW = 8, WM_ = 2), 64 columns = four waves of 64x32 (NW = 4, WM_ = 2), 96 columns (the 65..96-channel layers) = four
+// waves of 32x96 that split the rows only (NW = 4, WM_ = 4).
+template <int BN, int LW, int NW = 8, int WM_ = 2>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void conv_x3h_kernel(const ConvParams p) {
+    constexpr int BM = 128, NT = NW * 64, WM = WM_, WN = NW / WM_, MF = 32, ABL = 0, CK = 16;
     constexpr int kWTM = BM / WM, kWTN = BN / WN, kTM = kWTM / 32, kTN = kWTN / 32;
-    static_assert(BN == 128, "eight waves of 64x32");
+    static_assert(kWTM % 32 == 0 && kWTN % 32 == 0, "wave tile of whole 32x32 MFMA tiles");
     constexpr int W = 1 << LW, Wp = W + 2, R = BM / W, NH = (R + 2) * Wp;      // tile = R whole image rows; NH halo pixels
     static_assert(W <= 32 && BM % W == 0, "a 32-lane fragment group reads whole runs of 16 consecutive pixels");
     constexpr int PIX = 112;                                   // bytes per halo pixel: [3 planes][16 bf16] + 16 B pad
@@ -35,7 +37,8 @@ __global__ __launch_bounds__(512, 4) void conv_x3h_kernel(const ConvParams p) {
     constexpr int AI = (NH * 4 + NT - 1) / NT;                 // float4 staging units per thread and chunk
     constexpr int BP = BN * 32, BS = 3 * BP;                   // bytes per weight plane / per weight stage
     constexpr int kBUnits = 3 * BN * 2;
-    static_assert(AH % 16 == 0 && AI <= 3, "halo buffer");
+    constexpr int kBInstr = kBUnits / 64;                      // 1 KB LDS-DMA copies per weight stage: three per wave, waves 0 ..
+    static_assert(AH % 16 == 0 && AI <= 4 && kBUnits % 64 == 0 && kBInstr <= 3 * NW, "halo buffer / weight copies");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * AH + 2 * BS];
 
     DR_PIN_ARGS(p.x, p.x_cs, p.x_coff, p.Cin, p.B, p.H, p.w3, p.Kp, p.Np, p.zeros, p.nfast, p.gx, p.gy, p.Ng);
@@ -72,23 +75,25 @@ __global__ __launch_bounds__(512, 4) void conv_x3h_kernel(const ConvParams p) {
         a_lds[i] = live ? (unsigned)(hh * PIX + q * 8) : kDead;
     }
     const int a_q4 = (tid & 3) * 4;                            // first channel of this thread's units within a chunk (NT % 4 == 0)
-    // weight planes (conv_x3.h: [Kp/16][tap][Np][3][16] in HBM) by LDS-DMA: a stage is [plane][BN rows][2 slots of 16 B], 12 copies of 1 KB;
-    // waves 0-3 issue three each.  Lane L of copy q owns unit u = 64 q + L = (plane, row, physical slot) and fetches the logical slot
-    // physical ^ ((row >> 3) & 1) (the swizzle of conv_x3.h on the source side); rows beyond Np offer an out-of-range offset: zeros.
-    const bool b_wave = wave < 4;
+    static_assert(NT % 4 == 0, "a thread's units share their channel group");
+    // weight planes (conv_x3.h: [Kp/16][tap][Np][3][16] in HBM) by LDS-DMA: a stage is [plane][BN rows][2 slots of 16 B] = kBInstr copies
+    // of 1 KB; wave w issues copies 3 w .. 3 w + 2 (those that exist).  Lane L of copy q owns unit u = 64 q + L = (plane, row, physical
+    // slot) and fetches the logical slot physical ^ ((row >> 3) & 1) (the swizzle of conv_x3.h on the source side); rows beyond Np offer an
+    // out-of-range offset: zeros.
+    const int b_n = kBInstr - wave * 3 < 0 ? 0 : (kBInstr - wave * 3 > 3 ? 3 : kBInstr - wave * 3);     // copies of this wave (uniform)
     const P3Src srcB = p3_src(p.w3, 0, (size_t)9 * KT * p.Np * 96);
     unsigned b_voff[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int u = ((wave & 3) * 3 + j) * 64 + lane;
+        const int u = (wave * 3 + j) * 64 + lane;
         const int pl = u / (BN * 2), within = u % (BN * 2), row = within >> 1, ls = (within & 1) ^ ((row >> 3) & 1);
-        b_voff[j] = n0 + row < p.Np ? (unsigned)(((n0 + row) * 3 + pl) * 32 + ls * 16) : kP3Oob;
+        b_voff[j] = (u < kBUnits && n0 + row < p.Np) ? (unsigned)(((n0 + row) * 3 + pl) * 32 + ls * 16) : kP3Oob;
     }
-    const unsigned b_dst = (unsigned)(2 * AH + (wave & 3) * 3 * 1024);
+    const unsigned b_dst = (unsigned)(2 * AH + wave * 3 * 1024);
     unsigned b_soff = 0;
     const unsigned w_tile = (unsigned)p.Np * 96u;
 
-    float4 a_reg;                                               // one staging register set: unit i is fetched in tap 2 i + 1 and stored in tap 2 i + 3
+    float4 a_reg;                                               // one staging register set: unit i is fetched in tap 2 i and stored in tap 2 i + 2
     const bool ragged = (p.Cin & 3) != 0;
     auto load_a = [&](const int i, const int kc) __attribute__((always_inline)) {
         const bool ok = a_off[i] != kDead && kc + a_q4 < p.Cin;
@@ -110,10 +115,9 @@ __global__ __launch_bounds__(512, 4) void conv_x3h_kernel(const ConvParams p) {
         *reinterpret_cast<uint2*>(dst + a_lds[i] + 64) = h2;
     };
     auto dma_b = [&](const unsigned stage) __attribute__((always_inline)) {
-        if (b_wave) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) p3_dma16(srcB, b_voff[j], b_soff, lds, b_dst + stage * BS + j * 1024);
-        }
+        for (int j = 0; j < 3; ++j)
+            if (j < b_n) p3_dma16(srcB, b_voff[j], b_soff, lds, b_dst + stage * BS + j * 1024);
         b_soff += w_tile;
     };
 
@@ -180,8 +184,8 @@ __global__ __launch_bounds__(512, 4) void conv_x3h_kernel(const ConvParams p) {
 #undef X3H_READ_B
             }
             // the halo of chunk c + 1, one unit at a time through a_reg: stored two taps after it was requested, then the next one requested
-            if ((tap & 1) && tap >= 3 && (tap - 3) / 2 < AI && more_c) store_a((tap - 3) / 2, ah_next, (c + 1) * CK);
-            const bool fetch_a = (tap & 1) && tap / 2 < AI && more_c;
+            if (!(tap & 1) && tap >= 2 && (tap - 2) / 2 < AI && more_c) store_a((tap - 2) / 2, ah_next, (c + 1) * CK);
+            const bool fetch_a = !(tap & 1) && tap / 2 < AI && more_c;
             if (fetch_a) load_a(tap / 2, (c + 1) * CK);
             bpar ^= 1;
             // the weight copy issued at the top of this tap has landed (this wave's share; the halo fetch just issued may stay in flight),
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(512, 4) void conv_x3h_kernel(const ConvParams p) {
     constexpr int EP_TM = kTM, EP_TN = kTN;
     const int ep_m0 = m0 + wm * kWTM, ep_n0 = n0 + wn * kWTN;
     const unsigned ep_rows = 0xFFFFu;
-    constexpr int EP_BATCH_ROWS = 4;
+    constexpr int EP_BATCH_ROWS = NW == 8 ? 4 : 8;
     constexpr int EP_TS = MF, EP_NR = NR;
     const int ep_lg = lk, ep_lc = li;
     {

@@ -169,6 +169,12 @@ static int conv_tile_heuristic(const ConvParams& p) {
 // conv_x3.h (fp32-accurate products on the bf16 matrix cores, 128x128 tile): where it is used.  DR_CONV_X3: 0 = never,
 // 1 = the measured rule (default), 2 = wherever the kernel can run (tests)
 static int g_dbg_x3 = -1;            // test/bench hook (dr_dbg_force_x3): overrides DR_CONV_X3
+// conv_x3h.h: 3x3 layers whose 128-row tiles are whole rows of a 16- or 32-pixel-wide image keep the haloed input tile in LDS across
+// the nine taps (DR_X3_HALO=0 / dr_dbg_force_x3(7): conv_x3_kernel everywhere)
+static bool conv_x3h_shape(const ConvParams& p) {
+    static const bool halo_on = [] { const char* e = getenv("DR_X3_HALO"); return !(e && e[0] == '0'); }();
+    return halo_on && g_dbg_x3 != 7 && p.ksize == 3 && !p.rowmask && (p.W == 32 || p.W == 16) && (p.H * p.W) % 128 == 0;
+}
 bool conv_use_x3(const ConvParams& p) {
     static const int env = [] { const char* e = getenv("DR_CONV_X3"); return e ? atoi(e) : 1; }();
     const int mode = g_dbg_x3 >= 0 ? g_dbg_x3 : env;
@@ -187,6 +193,15 @@ bool conv_use_x3(const ConvParams& p) {
     // one 96-column block for the 65..96-channel layers (the hm3 / um-tower residuals and their input gradients) on deep grids;
     // DR_X3_BN96=0 leaves them on the fp32 16-column tiles
     static const bool bn96 = [] { const char* e = getenv("DR_X3_BN96"); return !(e && e[0] == '0'); }();
+    // the halo kernel wins from one workgroup per CU on (profiles/r06_x3h_rule.md: at 320 row blocks 1.38-1.85x the fp32 tiles, at 400 row
+    // blocks of 16x16 pixels 1.7-1.9x, at 80 equal): inference at B = 40 and the 16x16 level of a 200-crop window included
+    if (conv_x3h_shape(p) && p.Kp >= 64) {
+        const long rb = dr_ceil_div((int)M, 128);
+        if (ncols % 128 == 0) return rb * (ncols / 128) >= 256;
+        if (ncols == 96) return bn96 && rb >= 256;
+        if (ncols % 64 == 0) return bn64 && rb * (ncols / 64) >= 256;
+        return false;
+    }
     if (ncols == 96) return bn96 && dr_ceil_div((int)M, 128) >= 2 * min_wgs && (long)p.ksize * p.ksize * p.Kp >= 128;
     return bn64 && ncols % 64 == 0 && dr_ceil_div((int)M, 128) * (long)(ncols / 64) >= 2 * min_wgs && (long)p.ksize * p.ksize * p.Kp >= 128;
 }
@@ -260,13 +275,17 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         const bool ring = false;
 #endif
         const bool w4 = (variant & 4) || g_dbg_x3 == 5 || one_acc || ring;
-        // conv_x3h.h: 3x3 layers whose 128-row tiles are whole image rows keep the haloed input tile in LDS across the nine taps
-        // (DR_X3_HALO=0 / dr_dbg_force_x3(7): conv_x3_kernel everywhere)
-        static const bool halo_on = [] { const char* e = getenv("DR_X3_HALO"); return !(e && e[0] == '0'); }();
-        if (halo_on && g_dbg_x3 != 7 && p.ksize == 3 && !bn96 && !bn64 && !one_acc && !ring && !w4 && !p.rowmask && (p.W == 32 || p.W == 16) &&
-            (p.H * p.W) % 128 == 0) {
-            if (p.W == 32) DR_LAUNCH((conv_x3h_kernel<128, 5>), grid, dim3(512), 0, s, q);
-            else DR_LAUNCH((conv_x3h_kernel<128, 4>), grid, dim3(512), 0, s, q);
+        if (conv_x3h_shape(p) && !one_acc && !ring && !w4) {
+            if (bn96) {
+                if (p.W == 32) DR_LAUNCH((conv_x3h_kernel<96, 5, 4, 4>), grid, dim3(256), 0, s, q);
+                else DR_LAUNCH((conv_x3h_kernel<96, 4, 4, 4>), grid, dim3(256), 0, s, q);
+            } else if (bn64) {
+                if (p.W == 32) DR_LAUNCH((conv_x3h_kernel<64, 5, 4, 2>), grid, dim3(256), 0, s, q);
+                else DR_LAUNCH((conv_x3h_kernel<64, 4, 4, 2>), grid, dim3(256), 0, s, q);
+            } else {
+                if (p.W == 32) DR_LAUNCH((conv_x3h_kernel<128, 5>), grid, dim3(512), 0, s, q);
+                else DR_LAUNCH((conv_x3h_kernel<128, 4>), grid, dim3(512), 0, s, q);
+            }
             ++g_x3h_launches;
             return 0;
         }

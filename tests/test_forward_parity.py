@@ -93,6 +93,8 @@ X3_CASES = CONV_CASES + [
     # 3x3 on 16- / 32-pixel-wide images whose 128-row tiles are whole image rows: what conv_x3h.h takes (the haloed tile resident in LDS) --
     # one tile per image (every halo row outside), several tiles per image (halo rows from the neighbours), ragged Cin, one chunk only
     (1, 8, 16, 40, 128, 3), (2, 4, 32, 24, 128, 3), (2, 8, 32, 35, 256, 3), (1, 16, 16, 64, 128, 3), (3, 12, 32, 16, 128, 3),
+    # ... on its 96-column (65..96 channels), 64-column and ragged 128-column tiles
+    (1, 4, 32, 78, 78, 3), (2, 8, 16, 65, 65, 3), (1, 8, 32, 64, 64, 3), (1, 4, 32, 20, 200, 3),
 ]
 
 
@@ -112,15 +114,17 @@ def test_conv_x3_fp32_accurate_products_on_the_bf16_matrix_cores(be, case):
     mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if k == 1 else None
     yr, raw = ref_conv2d(x, w, scale, shift, True, res, mask, -0.5)
     outs = {}
-    halo = k == 3 and W in (16, 32) and (H * W) % 128 == 0 and (-(-Cout // 32) * 32) % 128 == 0      # conv_x3h.h takes the layer in modes 2 and 6 (no P3 input there: rule order)
+    halo = k == 3 and W in (16, 32) and (H * W) % 128 == 0      # conv_x3h.h takes the layer in mode 2
     for mode in (0, 2, 4, 5, 6, 7):                          # fp32 matrix cores | x3 (default: eight waves, halo kernel where it applies) | three-stage LDS ring | four waves | P3-stored input | no halo kernel
         try:
             assert be.dbg.dr_dbg_force_x3(mode) == 0
             n_p3, n_h = be.dbg.dr_dbg_p3_launches(), be.dbg.dr_dbg_x3h_launches()
             outs[mode] = be.conv2d(x, w, scale, shift, True, res, mask, -0.5, want_stats=True)
-            assert be.dbg.dr_dbg_x3h_launches() - n_h == (1 if mode == 2 and halo else 0)
-            # (whole 128-column blocks and at least two K-tiles: conv_p3_kernel itself must have run in mode 6, and only there)
-            assert be.dbg.dr_dbg_p3_launches() - n_p3 == (1 if mode == 6 and (-(-Cout // 32) * 32) % 128 == 0 and k * k * -(-Cin // 16) >= 2 else 0)
+            # (whole 128-column blocks and at least two K-tiles: conv_p3_kernel itself must have run in mode 6, and only there; the halo
+            # kernel in mode 2, and in mode 6 where conv_p3_kernel does not apply)
+            p3 = mode == 6 and (-(-Cout // 32) * 32) % 128 == 0 and k * k * -(-Cin // 16) >= 2
+            assert be.dbg.dr_dbg_p3_launches() - n_p3 == (1 if p3 else 0)
+            assert be.dbg.dr_dbg_x3h_launches() - n_h == (1 if halo and (mode == 2 or (mode == 6 and not p3)) else 0)
         finally:
             be.dbg.dr_dbg_force_x3(be.x3_default)
     e32, e3 = _rel(outs[0][0], yr), _rel(outs[2][0], yr)

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (before the library: torch brings its own HIP runtim
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from densereg_amd import _lib  # noqa: E402
 
-SHAPES = [(32, 256, 256, 3), (32, 128, 128, 3), (32, 512, 512, 3), (16, 256, 256, 3), (32, 64, 128, 3)]
+SHAPES = [(32, 256, 256, 3), (32, 128, 128, 3), (32, 78, 78, 3), (32, 65, 65, 3), (32, 64, 64, 3), (16, 256, 256, 3), (16, 64, 64, 3), (32, 64, 128, 3)]
 
 
 def main():

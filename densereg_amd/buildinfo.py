@@ -14,7 +14,7 @@ import re
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 # the kernels, and the host code that decides WHICH kernel runs with what grid (tile selection, slab plans, split-K fallbacks,
 # the executors): an edit there changes the bytes per launch just as an edit to a kernel does
-KERNEL_SOURCES = ('conv_igemm.h', 'conv_x3.h', 'conv_wgrad_x3.h', 'conv_epilogue.inc', 'conv_splitk.h', 'conv_wgrad.h', 'conv_wgrad16.h', 'conv_wgrad_bf16.h', 'conv_wgrad_tr.h', 'hg_fused.h',
+KERNEL_SOURCES = ('conv_igemm.h', 'conv_x3.h', 'conv_x3h.h', 'conv_p3.h', 'conv_wgrad_x3.h', 'conv_epilogue.inc', 'conv_splitk.h', 'conv_wgrad.h', 'conv_wgrad16.h', 'conv_wgrad_bf16.h', 'conv_wgrad_tr.h', 'hg_fused.h',
                   'train_kernels.h', 'kernels_misc.h', 'dr_platform.h', 'vote.h',
                   'densereg.cpp', 'train_exec.inc', 'pipeline.inc', 'net.h')
 

@@ -32,7 +32,6 @@
 
 namespace dr {
 
-typedef int dr_i32x4 __attribute__((ext_vector_type(4)));
 
 // ---- P3 storage -------------------------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int p3_cp(int C) { return (C + 15) & ~15; }
@@ -66,36 +65,7 @@ __global__ __launch_bounds__(256) void p3_split_kernel(const float* x, int x_cs,
     }
 }
 
-// ---- one 16-byte-per-lane LDS-DMA -------------------------------------------------------------------------------------------------
-constexpr unsigned kP3Oob = 0x80000000u;                    // per-lane offset of a lane that must read zeros (beyond num_records)
-#if defined(DR_EMU)
-struct P3Src { const unsigned char* base; };
-static inline P3Src p3_src(const void* base, long bias_bytes, size_t /*bytes*/) { return P3Src{reinterpret_cast<const unsigned char*>(base) - bias_bytes}; }
-static inline void p3_dma16(const P3Src& s, unsigned voff, unsigned soff, unsigned char* lds, unsigned lds_off) {
-    unsigned char* d = lds + lds_off + (threadIdx.x & 63) * 16;
-    if (voff & kP3Oob) memset(d, 0, 16); else memcpy(d, s.base + (size_t)voff + (size_t)soff, 16);
-}
-#define P3_WAIT_VM(n) ((void)0)
-#else
-struct P3Src { dr_i32x4 rsrc; };
-// raw buffer descriptor (stride 0) over [base - bias, base + bytes): the scalar offset of a K-tile may shift a pixel back by up to
-// one image row + one pixel (3x3 taps), so the base is biased down and the scalar offsets up -- both unsigned
-__device__ __forceinline__ P3Src p3_src(const void* base, long bias_bytes, size_t bytes) {
-    const unsigned long long a = (unsigned long long)reinterpret_cast<const unsigned char*>(base) - (unsigned long long)bias_bytes;
-    P3Src s;
-    s.rsrc[0] = (int)(unsigned)a;
-    s.rsrc[1] = (int)((unsigned)(a >> 32) & 0xFFFFu);
-    s.rsrc[2] = (int)(unsigned)(bytes + 2 * (size_t)bias_bytes);
-    s.rsrc[3] = 0x00020000;
-    return s;
-}
-__device__ __forceinline__ void p3_dma16(const P3Src& s, unsigned voff, unsigned soff, unsigned char* lds, unsigned lds_off) {
-    const unsigned dst = (unsigned)(unsigned long long)lds + lds_off;       // low half of the flat address of a __shared__ object = its LDS offset
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff), "s"(s.rsrc), "s"(soff) : "memory");
-}
-// (lgkmcnt(0): every fragment read of the tile has RETURNED before the barrier behind which its stage is overwritten)
-#define P3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)" ::: "memory")
-#endif
+// (the LDS-DMA primitive p3_dma16 / P3Src / P3_WAIT_VM: x3_dma.h)
 
 // The kernel.  BM = 128 rows, BN = 128 columns, eight waves of 64x32 (conv_x3_kernel's default shape: 128 VGPRs, four waves per SIMD,
 // two workgroups per CU with 72 KB of LDS each).

@@ -21,6 +21,7 @@
 //   Block = 256 threads = 2 x 2 waves; wave tile (BM/2) x (BN/2) of 32x32 MFMA tiles.  128x128: 12 fragment reads feed 24 MFMAs.
 #pragma once
 #include "conv_igemm.h"
+#include "x3_dma.h"
 
 namespace dr {
 
@@ -63,8 +64,12 @@ __host__ __device__ static inline void x3_split4(const float4 v, uint2& h0, uint
 // the waves per SIMD fit the register file: more MFMA chains to interleave with the staging of the next tile.
 // WM_ = 4 (with NW = 4): the waves split the rows only, each owns ALL BN columns -- the 96-column tile of the 65..96-channel layers
 // (three column tiles per wave; a 2 x 2 layout would need 64-column multiples).
-template <int BM, int BN, int LO = 1, int RING = 0, int NW = 4, int WM_ = 2>
+// BD = 1 (two-stage kernels): the weight planes of a K-tile go L2 -> LDS by an LDS-DMA hidden from hipcc (x3_dma.h: inline asm, explicit
+// wait before a raw s_barrier) instead of through registers: no staging registers (the loads were sunk to their ds_write at the 128-register
+// limit), no ds_write_b128, no 64-bit address selects -- the weight path of conv_x3h.h.
+template <int BM, int BN, int LO = 1, int RING = 0, int NW = 4, int WM_ = 2, int BD = 0>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_kernel(const ConvParams p) {
+    static_assert(BD == 0 || RING == 0, "the hidden weight copy belongs to the two-stage loop");
     constexpr int NT = NW * 64;                              // threads
     constexpr int WM = WM_, WN = NW / WM_, WK = 1, MF = 32, ABL = 0;
     constexpr int kWTM = BM / WM, kWTN = BN / WN, kTM = kWTM / 32, kTN = kWTN / 32;
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
     DR_PIN_ARGS(p.x, p.x_cs, p.x_coff, p.Cin, p.B, p.H, p.W, p.ksize, p.w3, p.Kp, p.Np, p.rowmask, p.zeros, p.nfast, p.gx, p.gy, p.Ng);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = BD ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;       // (BD: uniform -- LDS-DMA bases live in M0)
     const int wk = 0;
     const int wm = wave / WN;
     const int wn = wave % WN;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
             a_nv[i] = ok ? nv : 4;
         }
 #define X3_LOAD_B(i) *reinterpret_cast<const float4*>(b_ok[i] ? reinterpret_cast<const void*>(ld_w + b_off[i]) : reinterpret_cast<const void*>(p.zeros))
-        if constexpr (RING != 2) {                                         // (RING = 2 copies the weight planes by LDS-DMA: dma_b below)
+        if constexpr (RING != 2 && !BD) {                                  // (RING = 2 / BD copy the weight planes by LDS-DMA: dma_b / dma_bd below)
             b_reg0 = X3_LOAD_B(0);
             if constexpr (kBIters > 1) b_reg1 = X3_LOAD_B(1);
             if constexpr (kBIters > 2) b_reg2 = X3_LOAD_B(2);
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
             uint2* d2 = reinterpret_cast<uint2*>(&DR_AS(buf)[2][r][slot]) + (q & 1);
             *d0 = h0; *d1 = h1; *d2 = h2;
         }
-        if constexpr (RING != 2) {
+        if constexpr (RING != 2 && !BD) {
             float4* const bs = &DR_BS(buf)[0][0][0];
             if (kBUnits % NT == 0 || tid < kBUnits) bs[b_lds[0]] = b_reg0;
             if constexpr (kBIters > 1) { if (kBUnits % NT == 0 || tid + NT < kBUnits) bs[b_lds[1]] = b_reg1; }
@@ -239,6 +244,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
                 dr_glds16(bd_ok[i] ? reinterpret_cast<const float*>(dma_w + bd_off[i]) : p.zeros,
                           reinterpret_cast<float*>(&DR_BS(st)[0][0][0] + (wave + NW * i) * 64));
         dma_w += w_tile;
+    };
+
+    // BD: wave w issues the 1 KB copies 3 w .. 3 w + 2 of a stage's kBUnits / 64 (lane L of copy q = unit 64 q + L = (plane, row, physical
+    // slot), fetching the logical slot; rows beyond Np read zeros: x3_dma.h)
+    constexpr int kBInstr = kBUnits / 64;
+    static_assert(!BD || (kBUnits % 64 == 0 && kBInstr <= 3 * NW), "weight copies");
+    const P3Src srcB = p3_src(p.w3, 0, BD ? (size_t)T_total * p.Np * 96 : 0);
+    unsigned bq_voff[3];
+    const int bq_n = !BD ? 0 : kBInstr - wave * 3 < 0 ? 0 : (kBInstr - wave * 3 > 3 ? 3 : kBInstr - wave * 3);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int u = (wave * 3 + j) * 64 + lane;
+        const int pl = u / (BN * 2), within = u % (BN * 2), row = within >> 1, ls = (within & 1) ^ ((row >> 3) & 1);
+        bq_voff[j] = (BD && u < kBUnits && n0 + row < p.Np) ? (unsigned)(((n0 + row) * 3 + pl) * 32 + ls * 16) : kP3Oob;
+    }
+    unsigned bq_soff = 0;
+    auto dma_bd = [&](const int st) __attribute__((always_inline)) {
+        if constexpr (!BD) return;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < bq_n) p3_dma16(srcB, bq_voff[j], bq_soff, reinterpret_cast<unsigned char*>(&DR_BS(st)[0][0][0]), (unsigned)((wave * 3 + j) * 1024));
+        bq_soff += (unsigned)p.Np * 96u;
     };
 
     // Two accumulators per output tile: `acc` takes the leading products a0*b0, `lo` the five correction products (each <= 2^-8 of
@@ -317,13 +344,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
         }
         __syncthreads();                                                    // (the epilogue reuses stage 0 as scratch)
     } else {
-    load_tile();
+    load_tile(); dma_bd(0);
     store_tile(0, tail0);
-    __syncthreads();
+    if constexpr (BD) { P3_WAIT_VM(0); __builtin_amdgcn_s_barrier(); } else __syncthreads();
 
     auto k_tile = [&](const int buf, const bool more) __attribute__((always_inline)) {
         const bool was_tail = ld_kc + CK > p.Cin;                          // of the tile being fetched now
-        if (more) load_tile();
+        if (more) { load_tile(); dma_bd(buf ^ 1); }
         // fragments are read plane by plane, the planes 2 first: their registers are reused by the planes 1 (eight fragments live, not twelve)
         float4 a0[kTM], b0[kTN], ax[kTM], bx[kTN];
         X3_READ_A(a0, 0, buf); X3_READ_B(b0, 0, buf); X3_READ_A(ax, 2, buf); X3_READ_B(bx, 2, buf);
@@ -335,7 +362,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
         X3_MMA(LOACC, a0, bx);                                                // a0*b1
         X3_MMA(LOACC, ax, bx);                                                // a1*b1
         if (more) store_tile(buf ^ 1, was_tail);
-        __syncthreads();
+        if constexpr (BD) {                                                 // the tile's MFMAs are issued, then: the copy has landed, every LDS access returned
+            __builtin_amdgcn_sched_barrier(0);
+            P3_WAIT_VM(0);
+            __builtin_amdgcn_s_barrier();
+        } else __syncthreads();
     };
     const int T_pairs = T_total & ~1;
     for (int t = 0; t < T_pairs; t += 2) {

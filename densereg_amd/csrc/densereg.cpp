@@ -175,6 +175,11 @@ static bool conv_x3h_shape(const ConvParams& p) {
     static const bool halo_on = [] { const char* e = getenv("DR_X3_HALO"); return !(e && e[0] == '0'); }();
     return halo_on && g_dbg_x3 != 7 && p.ksize == 3 && !p.rowmask && (p.W == 32 || p.W == 16) && (p.H * p.W) % 128 == 0;
 }
+// conv_x3_kernel's weight tiles by a hidden LDS-DMA (conv_x3.h, BD); DR_X3_BD=0: through registers
+static bool x3_bd() {
+    static const bool on = [] { const char* e = getenv("DR_X3_BD"); return !(e && e[0] == '0'); }();
+    return on;
+}
 bool conv_use_x3(const ConvParams& p) {
     static const int env = [] { const char* e = getenv("DR_CONV_X3"); return e ? atoi(e) : 1; }();
     const int mode = g_dbg_x3 >= 0 ? g_dbg_x3 : env;
@@ -303,6 +308,7 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
             else if (ring) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 1>), grid, dim3(256), 0, s, q);
 #endif
             else if (w4) DR_LAUNCH((conv_x3_kernel<128, 128, 1>), grid, dim3(256), 0, s, q);
+            else if (x3_bd()) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1>), grid, dim3(512), 0, s, q);
             else DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8>), grid, dim3(512), 0, s, q);
         }
         return 0;

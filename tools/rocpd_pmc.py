@@ -46,7 +46,7 @@ def short_name(n):
     m = re.search(r'conv_igemm_kernel<(\d+), (\d+)', n)
     if m:
         return 'conv_igemm_%sx%s' % (m.group(1), m.group(2))
-    if 'conv_x3_kernel' in n:                                      # every tile / variant of conv_x3.h is one profile row (net.h: KID_CONV_X3)
+    if 'conv_x3_kernel' in n or 'conv_x3h_kernel' in n:            # every tile / variant of conv_x3.h and conv_x3h.h is one profile row (net.h: KID_CONV_X3)
         return 'conv_x3_128x128'
     if 'conv_splitk_kernel' in n:
         return 'conv_splitk_32x32'

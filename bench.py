@@ -151,9 +151,52 @@ def pmc_traffic(mode, kernel):
     return e['read_bytes_per_launch'] + e['write_bytes_per_launch'], prov
 
 
+# DR_BENCH_DRYRUN=1: the N > 1 HOST logic of this file without a GPU -- spawn_ranks, the launcher's environment, rank -> device
+# binding, the process group (gloo instead of RCCL), DataParallelTrainer's window step and its all-reduce of the flat gradient,
+# barrier + MAX-over-ranks timing, the one JSON line of rank 0 -- around an engine stand-in that runs NO kernels and does no
+# arithmetic (_DryRunEngine).  It exists so that the first real 8-GPU launch cannot die on host logic (tests/test_bench_dryrun.py);
+# its line says "dry_run": true and measures nothing.
+DRY_RUN = os.environ.get('DR_BENCH_DRYRUN') == '1'
+
+
+class _DryRunEngine:
+    """What bench.py and DataParallelTrainer call on an Engine, with no device and no numerics: the flat gradient is a CPU tensor that
+    ``backward`` fills with rank + 1, so the all-reduce that follows can be CHECKED (every element = 1 + 2 + ... + world)."""
+    pipeline = 1
+
+    def __init__(self, rank, world, n_param=4096):
+        self.rank, self.world = rank, world
+        self.device = torch.device('cpu')
+        self._grad = torch.zeros(n_param)
+        self.checked_reductions = 0
+
+    def set_precision(self, _p): pass
+    def load_params(self, _params): pass
+    def param_infos(self): return []
+    def norm_dm(self, dm, _com): return dm
+    def new(self, *shape): return torch.empty(*shape)
+    def flat_view(self, which):
+        assert which == 'grad'
+        return self._grad
+    def zero_grad(self): self._grad.zero_()
+    def set_groups(self, _g): pass
+    def groups_supported(self, _bg, _g): return True
+    def forward_train(self, _dm, _mode, _mask, _seed): pass
+    def loss(self, dm, _pose, _cfg, _com): return torch.zeros(4 * self._g(dm))
+    def _g(self, dm): return max(1, dm.shape[0] // self.micro_batch)
+    def backward(self, _b): self._grad.fill_(float(self.rank + 1))
+    def apply_adam(self, _lr, div, _step, _clip):
+        want = float(self.world * (self.world + 1) // 2)
+        assert bool((self._grad == want).all()), 'dry run: the all-reduce left %r, expected %r on every element' % (float(self._grad[0]), want)
+        assert div == float(self.sub_batch * self.world), div
+        self.checked_reductions += 1
+    def conv_flops_per_crop(self): return 0.0
+    def close(self): pass
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: run N ranks under torch.distributed.run (one per GPU, RCCL)."""
-    ngpu = torch.cuda.device_count()
+    ngpu = args.gpus if DRY_RUN else torch.cuda.device_count()
     if ngpu < args.gpus:
         sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) are visible; refusing to measure fewer ranks than asked\n'
                          % (args.gpus, ngpu))
@@ -185,16 +228,25 @@ def main():
         sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree\n' % (args.gpus, world))
         sys.exit(2)
     # one rank per GPU; if the launcher narrows device visibility to one GPU per process, that GPU is index 0
-    local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)                        # before the process group: RCCL binds to the current device
+    # (dry run: as many pretend devices as DR_BENCH_DRYRUN_DEVICES says -- 1 = the narrowed-visibility case -- default one per rank)
+    ndev = int(os.environ.get('DR_BENCH_DRYRUN_DEVICES', str(args.gpus))) if DRY_RUN else torch.cuda.device_count()
+    local = int(os.environ.get('LOCAL_RANK', '0')) % max(ndev, 1)
+    if not DRY_RUN:
+        torch.cuda.set_device(local)                    # before the process group: RCCL binds to the current device
     dist = None
     if world > 1 or os.environ.get('DR_FORCE_ALLREDUCE') == '1':
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group('gloo' if DRY_RUN else 'nccl', rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus or world == 1
-    dev = torch.device('cuda', local)
+    dev = torch.device('cpu') if DRY_RUN else torch.device('cuda', local)
+    if DRY_RUN:
+        if args.mode != 'train' or args.precision != 'f32':
+            sys.exit('bench.py: the dry run covers the training path (the one with a collective)')
+        args.no_profile = args.no_forward_vote = args.no_cpu_baseline = True
+        sys.stderr.write('bench.py DRY RUN rank %d/%d: LOCAL_RANK=%s -> pretend device %d of %d, backend gloo, MASTER %s:%s\n' % (
+            rank, world, os.environ.get('LOCAL_RANK', '0'), local, ndev, os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT')))
 
     from densereg_amd import _lib
     from densereg_amd.engine import Engine
@@ -214,7 +266,11 @@ def main():
         except ValueError as e:
             raise SystemExit('bench.py: %s' % e)
     MG = max(1, args.merge) if mode == 'infer' else 1       # forward(eval)+vote: batches per launch (ReplicaPool merge)
-    eng = Engine(S, F, J, HW, 3, B * max(G, MG), local, training=(mode == 'train'))
+    if DRY_RUN:
+        eng = _DryRunEngine(rank, world)
+        eng.micro_batch, eng.sub_batch = B, args.sub_batch
+    else:
+        eng = Engine(S, F, J, HW, 3, B * max(G, MG), local, training=(mode == 'train'))
     bf16 = args.precision == 'bf16'
     if bf16:
         eng.set_precision('bf16')
@@ -287,10 +343,12 @@ def main():
             p.flush()
 
     def barrier():
-        torch.cuda.synchronize(dev)
+        if not DRY_RUN:
+            torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not DRY_RUN:
+            torch.cuda.synchronize(dev)
 
     def timed(fn, steps=None, warmup=None):
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize, MAX over ranks (seconds)."""
@@ -446,14 +504,15 @@ def main():
     rccl = None
     if dist is not None:
         try:
-            rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            rccl = 'none (dry run over gloo)' if DRY_RUN else '.'.join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             rccl = 'unknown'
 
     if rank == 0:
         crops = B * world * args.steps
         out = {
-            'metric': 'depth-crops/sec %s, %d-stack fea=%d @%dx%d' % ('fwd+bwd' if mode == 'train' else 'fwd(eval)+vote', S, F, HW, HW),
+            'metric': ('DRY RUN (host plumbing over gloo, no kernels, measures nothing): ' if DRY_RUN else '') +
+                      'depth-crops/sec %s, %d-stack fea=%d @%dx%d' % ('fwd+bwd' if mode == 'train' else 'fwd(eval)+vote', S, F, HW, HW),
             'value': crops / dt, 'unit': 'crops/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
@@ -471,6 +530,10 @@ def main():
                        'conv_gflop_per_crop_fwd': eng_flops / 1e9},
             'roofline': roof, 'cpu_baseline': cpu, 'forward_vote': fwd_vote,
         }
+        if DRY_RUN:
+            out['dry_run'] = True
+            out['data'] = 'none (dry run)'
+            out['config']['checked_all_reduces'] = eng.checked_reductions
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.destroy_process_group()

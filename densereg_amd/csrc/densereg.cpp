@@ -759,7 +759,7 @@ static void free_all(dr_handle* h) {
         if (h->stat_part_l[l]) rt::dfree(h->stat_part_l[l]);
         if (h->stat_part2_l[l]) rt::dfree(h->stat_part2_l[l]);
     }
-    if (h->wg_stream) { if (rt::sync_stream(h->wg_stream) == 0) rt::stream_destroy(h->wg_stream); rt::event_destroy(h->wg_ready); rt::event_destroy(h->wg_done); }
+    if (h->wg_stream) { if (rt::sync_stream_bounded(h->wg_stream) == 0) rt::stream_destroy(h->wg_stream); rt::event_destroy(h->wg_ready); rt::event_destroy(h->wg_done); }
     for (auto& e : h->lane_ev) rt::event_destroy(e);
     for (auto& g : h->graphs) rt::graph_destroy(g.g);
     rt::stream_destroy(h->cap_stream);
@@ -1187,7 +1187,7 @@ int dr_finalize_params(dr_handle* h, dr_stream stream) {
     if (rc) return rc;
     rc = fold_bn(h, s);
     if (rc) return rc;
-    if (rt::sync_stream(s)) DR_FAIL(h, DR_E_DEVICE, "dr_finalize_params: stream sync failed");
+    if (rt::sync_stream_bounded(s)) DR_FAIL(h, DR_E_DEVICE, "dr_finalize_params: stream sync failed");
     DR_CHECK_LAUNCH(h);
     h->finalized = true;
     h->fold_is_eval = true;

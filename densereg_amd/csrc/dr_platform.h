@@ -28,6 +28,7 @@ inline int h2d(void* d, const void* h, size_t n, hipStream_t) { memcpy(d, h, n);
 inline int d2h(void* h, const void* d, size_t n, hipStream_t) { memcpy(h, d, n); return 0; }
 inline int d2d(void* d, const void* s, size_t n, hipStream_t) { memcpy(d, s, n); return 0; }
 inline int sync_stream(hipStream_t) { return 0; }
+inline int sync_stream_bounded(hipStream_t) { return 0; }
 inline int last_error(std::string*) { return 0; }
 struct Event { int dummy; };
 inline Event event_create() { return Event{0}; }
@@ -69,9 +70,11 @@ inline int h2d(void* d, const void* h, size_t n, hipStream_t s) { return hipMemc
 inline int d2h(void* h, const void* d, size_t n, hipStream_t s) { return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess ? 0 : -1; }
 inline int d2d(void* d, const void* s_, size_t n, hipStream_t s) { return hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1; }
 // Host-blocking wait, BOUNDED: a stream that does not drain within DR_SYNC_TIMEOUT_S seconds (default 120; 0 = wait forever) is
-// reported (-2, one line on stderr) instead of hanging the caller -- every wait of the library goes through here (parameter I/O,
-// mode switches, pipeline_drain, dr_destroy).  The poll is hipStreamQuery with a short sleep: these are rare paths.
-inline int sync_stream(hipStream_t s) {
+// reported (-2, one line on stderr) instead of hanging the caller.  ONLY for callers that act on the result (pipeline_drain,
+// dr_finalize_params, the stream-destroy paths: a stream that does not drain is leaked, not destroyed under its work) -- a caller
+// that goes on to read a host buffer, reuse a host table or free device memory must use sync_stream below, which never returns
+// before the stream has drained.  The poll is hipStreamQuery with a short sleep: these are rare paths.
+inline int sync_stream_bounded(hipStream_t s) {
     static const double limit = [] { const char* e = getenv("DR_SYNC_TIMEOUT_S"); return e ? atof(e) : 120.0; }();
     if (!(limit > 0.0) || hipPeekAtLastError() != hipSuccess) return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
     hipError_t e = hipStreamQuery(s);
@@ -90,6 +93,14 @@ inline int sync_stream(hipStream_t s) {
     }
     if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();     // (a poll's "not ready" is not an error of the caller's)
     return e == hipSuccess ? 0 : -1;
+}
+// Host-blocking wait that NEVER returns early: what every caller that depends on completion uses (device-to-host reads, host tables
+// the copy engine is still reading, dfree of buffers in flight).  A stream that exceeds DR_SYNC_TIMEOUT_S is NAMED on stderr (the
+// line of sync_stream_bounded) -- and then waited for: returning there would hand the caller an unfilled buffer as success.
+inline int sync_stream(hipStream_t s) {
+    const int rc = sync_stream_bounded(s);
+    if (rc != -2) return rc;
+    return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
 }
 inline int last_error(std::string* msg) {
     hipError_t e = hipGetLastError();

@@ -57,6 +57,9 @@ def train(S=2, F=128, dataset='icvl', steps=200, train_crops=2000, sub_batch=5, 
     Returns (params, loss history [steps, sub_batch, 4])."""
     J = DATASETS[dataset]['jnt_num']
     W = sub_batch * micro
+    if train_crops < W:
+        raise ValueError('train_crops=%d is less than one accumulation window of sub_batch x micro = %d crops' % (train_crops, W))
+    train_crops -= train_crops % W                  # whole windows only (a ragged tail would never be drawn)
     eng = Engine(S, F, J, 128, 3, W, device, training=True)
     eng.load_params(reference_init(eng, seed))
     trainer = DataParallelTrainer(eng, dataset=dataset, sub_batch=sub_batch)

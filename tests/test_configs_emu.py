@@ -28,3 +28,21 @@ def test_msra_j21_forward_vote_and_train_step_on_the_emulator(emu):
     masks = [rng.integers(0, 2, (1, 32, 32, 512)).astype(np.uint8) for _ in range(2)]
     h, _ = _run_step(emu, cfg, params, ndm, poses, cfgs, coms, masks)
     h.close()
+
+
+def test_train_step_with_the_x3_kernels_forced_on_every_layer_on_the_emulator(emu):
+    """The product's DEFAULT kernel selection runs the x3 family on the big layers (conv_x3.h, conv_x3h.h, conv_wgrad_x3.h); the emulator
+    suite otherwise forces the fp32-MFMA kernels for speed (tests/common.py).  This test keeps the handle-level wiring of the x3 family
+    covered without a GPU: one training micro-step of a small network (S=1, F=32, J=4) with dr_dbg_force_x3(2) -- the launcher rule, the
+    [chunk][tap][Np][3][16] weight planes of pack_all_kernel, the 128-row tiles' statistics rows, the halo kernel on the 32x32 3x3 layers,
+    the hidden weight copies, the x3 weight gradients -- against the oracle like every other training step."""
+    from tests.test_train_parity import _case as _train_case
+    cfg, params, ndm, poses, cfgs, coms = _train_case(1, 32, 4, 1)
+    n_h = emu.dbg.dr_dbg_x3h_launches()
+    try:
+        assert emu.dbg.dr_dbg_force_x3(2) == 0
+        h, _ = _run_step(emu, cfg, params, ndm, poses, cfgs, coms, None)
+        h.close()
+    finally:
+        emu.dbg.dr_dbg_force_x3(emu.x3_default)
+    assert emu.dbg.dr_dbg_x3h_launches() > n_h, 'the halo kernel did not run on the 3x3 layers of the 32x32 maps'

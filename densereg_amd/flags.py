@@ -41,6 +41,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--max_steps', type=int, default=0, help='stop after this many optimizer steps (0 = the reference schedule)')
     p.add_argument('--num_frames', type=int, default=0, help='test: number of synthetic frames (0 = dataset exact_num)')
     p.add_argument('--seed', type=int, default=20240)
+    p.add_argument('--synthetic_crops', type=int, default=4000,
+                   help='size of the synthetic stand-in dataset (no --data_dir): batch index i draws the seeded crops of index i modulo '
+                   'synthetic_crops // batch_size, generated once and kept on the host -- epochs over a finite set, as with the record files')
     p.add_argument('--groups', type=int, default=-1,
                    help='training: run the sub_batch micro-steps of an accumulation window as one pass of launches (dr_set_groups): '
                    '-1 = where it pays (parallel.window_groups), 0/1 = one micro-step per pass, sub_batch = always')

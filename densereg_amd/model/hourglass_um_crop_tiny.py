@@ -39,7 +39,9 @@ from ..parallel import DataParallelTrainer, check_world, decay_steps, per_rank_b
 
 
 class SyntheticDataset:
-    """Stand-in for data.icvl/nyu/msra: camera, joint count, sizes; batches come from make_crops."""
+    """Stand-in for data.icvl/nyu/msra: camera, joint count, sizes; batches come from make_crops.  A FINITE set like the record files:
+    batch ``index`` holds the seeded crops of ``index % (synthetic_crops // batch_size)``, synthesised once (2.8 ms of numpy per crop
+    on the host: 350 crops/s against the 3200 the training step consumes) and kept -- later epochs cost a dictionary lookup."""
 
     def __init__(self, name: str, subset: str, rank: int = 0, hw: int = 128):
         ds = DATASETS[name]
@@ -48,9 +50,16 @@ class SyntheticDataset:
         self.cfg = (ds['fx'], ds['fy'], ds['cx'], ds['cy'], ds['w'], ds['h'])
         self.approximate_num = ds['approximate_num']
         self.exact_num = ds['exact_num']
+        self._kept = {}
 
     def batch(self, batch_size: int, index: int):
-        return make_crops(batch_size, self.name, seed=flags.FLAGS.seed + 7919 * index, rank=self.rank, hw=self.hw)
+        period = max(1, int(getattr(flags.FLAGS, 'synthetic_crops', 4000)) // batch_size)
+        key = (batch_size, index % period, flags.FLAGS.seed)
+        hit = self._kept.get(key)
+        if hit is None:
+            hit = make_crops(batch_size, self.name, seed=flags.FLAGS.seed + 7919 * key[1], rank=self.rank, hw=self.hw)
+            self._kept[key] = hit
+        return hit
 
 
 class JointDetectionModel(object):
@@ -164,40 +173,111 @@ def train(model: JointDetectionModel, dist=None, log=sys.stdout):
         if log:
             print('[train] restored step %d (%d unexpected names in the checkpoint)' % (start_step, len(rep['unexpected'])), file=log)
     aug_rng = np.random.default_rng(F.seed + (dist.get_rank() if dist is not None else 0))
-    for step in range(start_step, max_steps):
-        start = time.time()
+    # The reference's step (train_single_gpu.py:138-158) is "sub_batch x (fetch a batch, sess.run, assert not NaN), sess.run(train_op)":
+    # the host waits for every micro-step's loss before it prepares the next batch.  Here the device must never wait for the host:
+    #   * a producer thread prepares the host side of window k+1 (crop synthesis / record decode: _dataset.batch) while the device runs
+    #     window k -- the queue runs one window ahead (the queue-runner role of data/dataset_base.py);
+    #   * the losses of window k are READ (the only device -> host synchronisation of the loop) after window k+1 has been queued; the
+    #     NaN assert of :147 therefore fires one window late -- one optimizer step has been applied on top of the diverged one, nothing
+    #     is saved in between (the checkpoint of a step is written after its losses were checked).
+    import queue
+    import threading
+    todo = queue.Queue(maxsize=2)
+    stop = threading.Event()
+
+    def produce():
+        m = start_step * F.sub_batch
+        try:
+            if model.device.type == 'cuda':
+                torch.cuda.set_device(model.device)                         # (record datasets decode on the device: this thread's current device)
+            for _step in range(start_step, max_steps):
+                if stop.is_set():
+                    return
+                todo.put([model._dataset.batch(model.rank_batch, m + k) for k in range(F.sub_batch)])
+                m += F.sub_batch
+        except BaseException as e:                                          # (the consumer re-raises it)
+            todo.put(e)
+
+    producer = threading.Thread(target=produce, name='densereg-batches', daemon=True)
+    producer.start()
+    micro = start_step * F.sub_batch
+    pending = None                                                          # (step, start time, losses on the device) of the window in flight
+    t_first = t_steady = None
+    # windows left out of the steady-state rate: the first launches, and the first epoch of a synthetic set (its crops are being synthesised)
+    n_warm = 2 + (-(-int(getattr(F, 'synthetic_crops', 0)) // (model.rank_batch * F.sub_batch)) if isinstance(model._dataset, SyntheticDataset) else 0)
+
+    def settle(entry):
+        """read a finished window's losses: the asserts and the log line of the reference's loop"""
+        st, t0, losses, n_crops = entry
         ave_loss = 0.0
-        window = []
-        for _ in range(F.sub_batch):
-            dm, poses, cfgs, coms, _n = model._dataset.batch(model.rank_batch, micro)
-            d_dm, d_pose, d_cfg, d_com = model._t(dm), model._t(poses), model._t(cfgs), model._t(coms)
-            if F.is_aug:                                                    # hourglass_um_crop_tiny.py:332-333
-                d_dm, d_pose = preprocess.data_aug(d_dm, d_pose, d_cfg, d_com, generator=aug_rng)
-            normed = model.engine.norm_dm(d_dm, d_com)
-            if model.window_groups > 1:                                     # the window runs as one pass once it is complete
-                window.append((normed, d_pose, d_cfg, d_com))
-                micro += 1
-                continue
-            losses = trainer.micro_step(normed, d_pose, d_cfg, d_com, seed=micro)
-            loss_value = float(losses.sum().item())
+        for loss_value in losses.reshape(-1, 4).sum(dim=1).tolist():        # (blocks until that window's launches are done)
             assert not np.isnan(loss_value), 'Model diverged with loss = NaN'          # :147
             ave_loss += loss_value
-            micro += 1
-        if window:
-            parts = [torch.cat([w[k] for w in window]) for k in range(4)]
-            losses = trainer.window_step(*parts, seed=micro - F.sub_batch)             # [sub_batch, 4]: one row per micro-step
-            for loss_value in losses.sum(dim=1).tolist():
-                assert not np.isnan(loss_value), 'Model diverged with loss = NaN'      # :147
-                ave_loss += loss_value
         ave_loss /= F.sub_batch
-        duration = time.time() - start
-        if log and step % 5 == 0:
+        duration = time.time() - t0
+        if log and st % 5 == 0:
             print('[model/train] %s: step %d/%d, loss = %.3f, %.3f sec/batch, %.3f sec/sample'
-                  % (datetime.now(), step, max_steps, ave_loss, duration, duration / (F.batch_size * F.sub_batch)), file=log)
-        if F.save_every > 0 and ((step + 1) % F.save_every == 0 or step + 1 == max_steps):       # :170-172
-            if dist is None or dist.get_rank() == 0:
-                os.makedirs(model.train_dir, exist_ok=True)
-                model.engine.save_checkpoint(os.path.join(model.train_dir, 'model.ckpt-%d' % (step + 1)), global_step=step + 1)
+                  % (datetime.now(), st, max_steps, ave_loss, duration, duration / (F.batch_size * F.sub_batch)), file=log)
+
+    try:
+        for step in range(start_step, max_steps):
+            host = todo.get()
+            if isinstance(host, BaseException):
+                raise host
+            start = time.time()
+            if t_first is None:
+                t_first = start
+            if step == start_step + n_warm:
+                if model.device.type == 'cuda':
+                    torch.cuda.synchronize(model.device)
+                t_steady = time.time()
+            window, step_losses = [], []
+            for dm, poses, cfgs, coms, _n in host:
+                d_dm, d_pose, d_cfg, d_com = model._t(dm), model._t(poses), model._t(cfgs), model._t(coms)
+                if F.is_aug:                                                # hourglass_um_crop_tiny.py:332-333
+                    d_dm, d_pose = preprocess.data_aug(d_dm, d_pose, d_cfg, d_com, generator=aug_rng)
+                normed = model.engine.norm_dm(d_dm, d_com)
+                if model.window_groups > 1:                                 # the window runs as one pass once it is complete
+                    window.append((normed, d_pose, d_cfg, d_com))
+                else:
+                    step_losses.append(trainer.micro_step(normed, d_pose, d_cfg, d_com, seed=micro).reshape(4))
+                micro += 1
+            if window:
+                parts = [torch.cat([w[k] for w in window]) for k in range(4)]
+                losses = trainer.window_step(*parts, seed=micro - F.sub_batch)         # [sub_batch, 4]: one row per micro-step
+            else:
+                losses = torch.stack(step_losses)
+            if pending is not None:
+                settle(pending)                                             # window k-1, while window k runs
+            pending = (step, start, losses, F.batch_size * F.sub_batch)
+            if F.save_every > 0 and ((step + 1) % F.save_every == 0 or step + 1 == max_steps):   # :170-172
+                settle(pending)                                             # a checkpoint is written after ITS losses were checked
+                pending = None
+                if dist is None or dist.get_rank() == 0:
+                    os.makedirs(model.train_dir, exist_ok=True)
+                    model.engine.save_checkpoint(os.path.join(model.train_dir, 'model.ckpt-%d' % (step + 1)), global_step=step + 1)
+        if pending is not None:
+            settle(pending)
+    finally:
+        stop.set()
+        while producer.is_alive():                                          # unblock a producer waiting on a full queue
+            try:
+                todo.get_nowait()
+            except queue.Empty:
+                pass
+            producer.join(0.05)
+    if log and t_first is not None and max_steps > start_step:
+        if model.device.type == 'cuda':
+            torch.cuda.synchronize(model.device)
+        el = time.time() - t_first
+        per_step = F.batch_size * F.sub_batch // (dist.get_world_size() if dist is not None else 1)
+        n = (max_steps - start_step) * per_step
+        msg = '[train] %d optimizer steps, %d crops on this rank in %.3f s: %.1f crops/s end to end (host batches + copies + augmentation + step)' % (
+            max_steps - start_step, n, el, n / el)
+        if t_steady is not None and max_steps - start_step > n_warm:
+            ns = (max_steps - start_step - n_warm) * per_step
+            msg += '; after the first %d windows: %.1f crops/s' % (n_warm, ns / (time.time() - t_steady))
+        print(msg, file=log)
     return trainer
 
 
@@ -297,7 +377,11 @@ def main(argv=None):
         val_dataset = SyntheticDataset(F.dataset, 'testing', rank, F.in_hw)
     if F.is_train:
         check_world(F.num_gpus, world)
-    eng = um_v1.get_engine(dataset.jnt_num, F.in_hw, per_rank_batch(F.batch_size, world if F.is_train else 1), local, bool(F.is_train))
+    # the engine the model class will ask for (same cache key AND capacity: a training window that runs as one pass needs
+    # rank_batch x sub_batch rows, JointDetectionModel.__init__) gets its random-init weights here
+    rb = per_rank_batch(F.batch_size, world if F.is_train else 1)
+    cap = rb * (window_groups(rb, F.sub_batch, F.in_hw, getattr(F, 'groups', -1)) if F.is_train else 1)
+    eng = um_v1.get_engine(dataset.jnt_num, F.in_hw, cap, local, bool(F.is_train))
     eng.load_params(_random_params(eng))
     if F.is_train:
         run_train(dataset, val_dataset, dist, local)

@@ -323,3 +323,72 @@ def test_engine_checkpoint_round_trip_with_adam(gpu, tmp_path):
     # 1e-4 of a tensor's max (see test_lanes_match_single_stream); measured here 1e-6 .. 9e-5
     assert worst < 1e-3, worst
     a.close(); b.close()
+
+
+def test_training_driver_keeps_one_window_queued_ahead_of_the_loss_check(monkeypatch, tmp_path):
+    """``train()`` (train_single_gpu.py:138-158 re-ordered): window k+1 is QUEUED before the losses of window k are read (the only
+    device -> host synchronisation), a checkpoint is written only after its own window's losses were checked, a NaN loss still stops
+    the run (one window late), and the producer thread ends with the loop.  A stand-in trainer records the order of events."""
+    import io
+    import threading
+
+    import torch
+    from densereg_amd import flags
+    from densereg_amd.model import hourglass_um_crop_tiny as M
+    events = []
+
+    class _Losses:
+        """losses of one window 'on the device': reading them is an event"""
+        def __init__(self, k, bad=False): self.k, self.bad = k, bad
+        def reshape(self, *s): return self
+        def sum(self, dim=1): return self
+        def tolist(self):
+            events.append(('read', self.k))
+            return [float('nan') if self.bad else 1.0] * 2
+
+    class _Trainer:
+        def __init__(self, eng, dataset, sub_batch, dist=None):
+            self.global_step, self.k, self.nan_at = 0, 0, getattr(eng, 'nan_at', -1)
+        def window_step(self, dm, pose, cfg, com, seed=0):
+            events.append(('queue', self.k, int(dm.shape[0]), seed))
+            self.k += 1
+            self.global_step += 1
+            return _Losses(self.k - 1, bad=(self.k - 1 == self.nan_at))
+
+    class _Eng:
+        def norm_dm(self, dm, com): return dm
+        def save_checkpoint(self, path, global_step): events.append(('save', global_step))
+
+    class _DS:
+        name = 'nyu'
+        def batch(self, bs, index):
+            return (np.full((bs, 4, 4, 1), index, np.float32), np.zeros((bs, 42), np.float32), np.zeros((bs, 6), np.float32),
+                    np.zeros((bs, 3), np.float32), ['f'] * bs)
+
+    class _Model:
+        engine, _dataset, device = _Eng(), _DS(), torch.device('cpu')
+        rank_batch, window_groups, decay_steps, lr_decay_factor, init_lr, max_steps = 8, 2, 1.0, 0.1, 1e-3, 4
+        train_dir = str(tmp_path)
+        def _t(self, a): return torch.from_numpy(np.ascontiguousarray(a, np.float32))
+
+    monkeypatch.setattr(M, 'DataParallelTrainer', _Trainer)
+    flags.parse(['--dataset', 'nyu', '--is_train', 'True', '--batch_size', '8', '--sub_batch', '2', '--max_steps', '4', '--is_aug', 'False',
+                 '--save_every', '2'])
+    try:
+        log = io.StringIO()
+        M.train(_Model(), log=log)
+        # every window holds its two micro-batches (seeds 0, 2, 4, 6 name the first micro-step of each); window 1 is queued BEFORE the
+        # losses of window 0 are read; the checkpoint of step 2 comes after the losses of window 1 (its own), not before
+        assert events == [('queue', 0, 16, 0), ('queue', 1, 16, 2), ('read', 0), ('read', 1), ('save', 2),
+                          ('queue', 2, 16, 4), ('queue', 3, 16, 6), ('read', 2), ('read', 3), ('save', 4)], events
+        assert 'crops/s end to end' in log.getvalue()
+        # a diverged window stops the run when its losses are read, i.e. after the next window was queued -- and nothing is saved on top of it
+        events.clear()
+        m = _Model()
+        m.engine.nan_at = 1
+        with pytest.raises(AssertionError, match='NaN'):
+            M.train(m, log=None)
+        assert ('queue', 1, 16, 2) in events and ('read', 1) in events and not any(e[0] == 'save' for e in events)
+        assert not any(t.name == 'densereg-batches' and t.is_alive() for t in threading.enumerate())
+    finally:
+        flags.parse([])

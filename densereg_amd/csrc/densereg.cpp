@@ -1574,9 +1574,38 @@ int dr_infer(dr_handle* h, int B, const float* dm, const float* cfg, const float
 int dr_read_activation(dr_handle* h, const char* scope, int B, float* host, size_t count) {
     if (!h || !scope || !host) return DR_E_INVALID;
     if (pipeline_drain(h)) DR_FAIL(h, DR_E_DEVICE, "a micro-step slot's stream did not drain");
+    // "<scope>#raw": the layer's output BEFORE BatchReNorm (kept by a training forward: the backward pass needs it); "<scope>#fold":
+    // [scale | shift], 2 * cout floats, the multiply-add that training forward applied to it (micro-batch group 0).  What a ReLU of
+    // that forward decided is then exact on the host: raw * scale + shift > 0 (tests/test_train_parity.py, the switch-free gradient test).
+    std::string want(scope);
+    int part = 0;
+    if (want.size() > 4 && want.compare(want.size() - 4, 4, "#raw") == 0) { part = 1; want.resize(want.size() - 4); }
+    else if (want.size() > 5 && want.compare(want.size() - 5, 5, "#fold") == 0) { part = 2; want.resize(want.size() - 5); }
     for (size_t oi = 0; oi < h->ops.size(); ++oi) {
         const Op& op = h->ops[oi];
-        if ((op.kind != OP_CONV && op.kind != OP_STEM) || h->convs[op.conv].name != scope) continue;
+        if ((op.kind != OP_CONV && op.kind != OP_STEM) || h->convs[op.conv].name != want) continue;
+        if (part) {
+            const ConvLayer& c = h->convs[op.conv];
+            if (!c.bn || !h->last_forward_train || !c.raw || c.raw->is_bf16) DR_FAIL(h, DR_E_STATE, "dr_read_activation: %s needs a BatchReNorm layer after an fp32 training forward", scope);
+            if (part == 2) {
+                if (count != 2 * (size_t)c.cout) DR_FAIL(h, DR_E_INVALID, "dr_read_activation: %s has %d elements, got %zu", scope, 2 * c.cout, count);
+                rt::sync_stream(nullptr);
+                rt::d2h(host, h->fold + c.fold_off, count * sizeof(float), nullptr);
+                rt::sync_stream(nullptr);
+                DR_CHECK_LAUNCH(h);
+                return DR_OK;
+            }
+            const long Mr = (long)B * c.H * c.W;
+            if (count != (size_t)Mr * c.cout) DR_FAIL(h, DR_E_INVALID, "dr_read_activation: %s has %zu elements, got %zu", scope, (size_t)Mr * c.cout, count);
+            if (count > h->n_scratch) DR_FAIL(h, DR_E_STATE, "scratch too small");
+            DR_LAUNCH(copy_channels_kernel, dim3(grid_for(Mr * c.cout)), dim3(256), 0, (hipStream_t) nullptr, (const float*)c.raw->p,
+                      c.raw->cs, 0, h->scratch, c.cout, 0, Mr, c.cout, 0);
+            rt::sync_stream(nullptr);
+            rt::d2h(host, h->scratch, count * sizeof(float), nullptr);
+            rt::sync_stream(nullptr);
+            DR_CHECK_LAUNCH(h);
+            return DR_OK;
+        }
         if (!h->last_forward_train && h->last_eval_fused)
             for (const FusedRegion& fr : h->fused)
                 if ((int)oi >= fr.first_op && (int)oi < fr.last_op)          // (the region's last conv IS written: its output tensor)

@@ -11,8 +11,12 @@
 // 4x4x4 start cell (ties -> LAST cell, tf.where(...)[-1]) and ten mean-shift iterations.
 // HBM-bound by construction: (5J+1)*npix*4 B read per crop (332 kB for J=16), 12J B written.
 //
-// Arithmetic is fp32 in the reference's op order with contraction off, so the only deviations from
-// the oracle are exp() ulps.  Documented choices: an out-of-range re-projected
+// Arithmetic is fp32 in the reference's op order with contraction off, and the one transcendental -- the mean-shift kernel weight
+// exp(-d^2 / 2 sigma^2) -- is vote_exp below: a FIXED sequence of IEEE fp32 multiplies and adds (the Cephes / Eigen pexp<float>
+// polynomial, which is what tf.exp runs on the reference's CPU path), restated operation by operation in oracle/pose.py::exp_f32.
+// So the vote has NO deviation from the oracle: identical maps give bit-identical joints (tests/test_gpu_fullsize.py); a libm expf
+// here differed from numpy's by an ulp, and ten mean-shift iterations between two candidate clusters amplified that ulp to 0.3 mm
+// on a handful of knife-edge joints (rounds 1-5).  Documented choices: an out-of-range re-projected
 // pixel contributes weight 0 (TF-GPU gather_nd), and a zero/non-finite kernel mass keeps the centre.
 #pragma once
 #include "dr_platform.h"
@@ -32,6 +36,32 @@ struct VoteParams {
 
 constexpr int kVoteJC = 4;         // joints per workgroup (= waves)
 constexpr int kVoteMaxPix = 4096;  // LDS: 4 joints x 4096 px x 4 B = 64 KiB
+
+// exp(x) for x <= 0 (NaN propagates; x <= -87: 0, the result would be below the smallest normal).  Cody-Waite reduction x = n ln2 + r,
+// degree-5 polynomial in r (Cephes expf / Eigen pexp<float> coefficients), scaling by 2^n through the exponent field; every step
+// one correctly rounded fp32 operation, no fused multiply-add: bit-reproducible by any IEEE implementation.
+__device__ __forceinline__ float vote_exp(float x) {
+#pragma clang fp contract(off)
+    if (!(x > -87.0f)) return x != x ? x : 0.0f;
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    float q = 1.9875691500e-4f;
+    q = q * r + 1.3981999507e-3f;
+    q = q * r + 8.3334519073e-3f;
+    q = q * r + 4.1665795894e-2f;
+    q = q * r + 1.6666665459e-1f;
+    q = q * r + 5.0000001201e-1f;
+    q = q * (r * r) + r;
+    q = q + 1.0f;
+    const int e = (int)n + 127;                                  // n >= -126: a normal power of two
+#if defined(DR_EMU)
+    float s; { const unsigned u = (unsigned)e << 23; memcpy(&s, &u, 4); }
+#else
+    const float s = __builtin_bit_cast(float, (unsigned)e << 23);
+#endif
+    return q * s;
+}
 
 __device__ __forceinline__ void vote_argmax_first(float& v, int& idx) {
     // wave-wide (max value, then min index)
@@ -187,7 +217,7 @@ __global__ __launch_bounds__(256) void vote_kernel(const VoteParams p) {
         for (int i = 0; i < 5; ++i) {
             const float d0 = cp[i][0] - ctr[0], d1 = cp[i][1] - ctr[1], d2 = cp[i][2] - ctr[2];
             float s = (d0 * d0 + d1 * d1) + d2 * d2;
-            s = expf(inv_sigma * s) * cw[i];
+            s = vote_exp(inv_sigma * s) * cw[i];
             a0 = a0 + cp[i][0] * s;
             a1 = a1 + cp[i][1] * s;
             a2 = a2 + cp[i][2] * s;

@@ -218,7 +218,9 @@ int dr_set_precision(dr_handle* h, int precision);
 int dr_set_fusion(dr_handle* h, int on);
 
 /* ---- introspection (tests / profiling) ----------------------------------------------------------- */
-/* Post-activation output of conv `scope` (e.g. "Conv_12") of the last forward as dense NHWC. */
+/* Post-activation output of conv `scope` (e.g. "Conv_12") of the last forward as dense NHWC.  After an fp32 dr_forward_train, for a
+ * BatchReNorm layer: "<scope>#raw" = its output before BatchReNorm (count = B*H*W*cout), "<scope>#fold" = [scale | shift] (count =
+ * 2*cout), the multiply-add that forward applied to it (micro-batch group 0) -- together what every ReLU of that forward decided. */
 int dr_read_activation(dr_handle* h, const char* scope, int B, float* host, size_t count);
 /* Algorithmic conv FLOPs per crop (forward), SURVEY section 8(d). */
 double dr_conv_flops_per_crop(const dr_handle* h);

@@ -106,8 +106,14 @@ class TorchOps(OpsBase):
 
     def __init__(self, cfg: NetConfig, params: Dict[str, torch.Tensor], is_training: bool,
                  dropout_masks: Optional[List[torch.Tensor]] = None, dtype=torch.float32,
-                 record: Optional[dict] = None, conv_operands: str = 'f32'):
+                 record: Optional[dict] = None, conv_operands: str = 'f32', switches: Optional[dict] = None):
         super().__init__(cfg)
+        # ``switches`` (tests only): the DISCRETE decisions of another evaluation of the same graph, injected so that two evaluations in
+        # different precisions take the same branches and what is left between their gradients is arithmetic alone --
+        #   switches['relu'](conv name)  -> NHWC bool array: which units of that conv's ReLU are open (replaces torch.relu)
+        #   switches['act'](conv name)   -> NHWC array of what the other evaluation stored for that conv (after its residual add): a
+        #                                   max-pool takes its argmax positions from THAT tensor (first maximum in scan order)
+        self.switches = switches
         # 'bf16': what a bf16 matrix-core path computes (BASELINE config 5; include/densereg.h dr_set_precision) --
         # both operands of every k != 7 convolution rounded to bfloat16 (nearest even), products and sums in fp32
         self.conv_operands = conv_operands
@@ -119,6 +125,8 @@ class TorchOps(OpsBase):
         self.bn_updates: Dict[str, torch.Tensor] = {}
         self.record = record        # name -> NHWC numpy of every conv output (post activation)
         self._producer = {}         # id(tensor) -> (conv name, tensor) for '+res' records
+        self._stored = {}           # id(tensor) -> (conv name, tensor): what the engine stores under that conv's name (its output, or the
+                                    # residual sum fused behind it) -- the max-pools' inputs, for ``switches``
 
     def channels(self, x):
         return x.shape[1]
@@ -165,21 +173,29 @@ class TorchOps(OpsBase):
         else:
             y = y + self.p[name + '/biases'].view(1, -1, 1, 1)
         if relu:
-            y = torch.relu(y)
+            if self.switches is not None:
+                open_ = torch.from_numpy(np.ascontiguousarray(self.switches['relu'](name))).permute(0, 3, 1, 2)
+                y = y * open_.to(y.dtype)
+            else:
+                y = torch.relu(y)
         if self.record is not None:
             self.record[name] = y.detach().permute(0, 2, 3, 1).contiguous().numpy()
+        if self.record is not None or self.switches is not None:
             self._producer[id(y)] = (name, y)
+            self._stored[id(y)] = (name, y)
         return y
 
     def add(self, a, b):
         out = a + b
-        if self.record is not None:
+        if self.record is not None or self.switches is not None:
             # the HIP engine fuses the residual add into the producing conv's epilogue: also record
             # '<conv>+res' so tests can compare what the engine stores for that conv.
             for t in (a, b):
                 ent = self._producer.get(id(t))
                 if ent is not None and ent[1] is t:
-                    self.record[ent[0] + '+res'] = out.detach().permute(0, 2, 3, 1).contiguous().numpy()
+                    if self.record is not None:
+                        self.record[ent[0] + '+res'] = out.detach().permute(0, 2, 3, 1).contiguous().numpy()
+                    self._stored[id(out)] = (ent[0], out)            # (the conv whose stored output this sum is)
                     break
         return out
 
@@ -187,9 +203,17 @@ class TorchOps(OpsBase):
         H, W = x.shape[2], x.shape[3]
         pt, pb = same_pad(H, k, s)
         pl, pr = same_pad(W, k, s)
-        if pt or pb or pl or pr:
-            x = F.pad(x, (pl, pr, pt, pb), value=float('-inf'))
-        return F.max_pool2d(x, k, s)
+        pad = lambda t: F.pad(t, (pl, pr, pt, pb), value=float('-inf')) if (pt or pb or pl or pr) else t
+        if self.switches is not None:
+            # the other evaluation's choice of the maximum of every window (first maximum in scan order, as torch reports it), applied
+            # to THIS evaluation's values
+            ent = self._stored.get(id(x))
+            assert ent is not None and ent[1] is x, 'max_pool input is not a stored conv output'
+            other = torch.from_numpy(np.ascontiguousarray(self.switches['act'](ent[0]))).permute(0, 3, 1, 2)
+            _, idx = F.max_pool2d(pad(other), k, s, return_indices=True)
+            xp = pad(x)
+            return xp.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+        return F.max_pool2d(pad(x), k, s)
 
     def upsample2(self, x):
         return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
@@ -236,10 +260,10 @@ def to_torch_params(params: Dict[str, np.ndarray], dtype=torch.float32, requires
 
 
 def detect_net(cfg: NetConfig, tparams, dm_nhwc: torch.Tensor, is_training: bool,
-               dropout_masks=None, record=None, conv_operands='f32'):
+               dropout_masks=None, record=None, conv_operands='f32', switches=None):
     """um_v1.detect_net: dm (B,H,W,1) normalised -> end_points with NHWC tensors + TorchOps."""
     dtype = dm_nhwc.dtype
-    ops = TorchOps(cfg, tparams, is_training, dropout_masks, dtype, record, conv_operands)
+    ops = TorchOps(cfg, tparams, is_training, dropout_masks, dtype, record, conv_operands, switches)
     hm, hm3, um = walk_detect_net(ops, dm_nhwc.permute(0, 3, 1, 2))
     nhwc = lambda t: t.permute(0, 2, 3, 1)
     return {'hm_outs': [nhwc(t) for t in hm], 'hm3_outs': [nhwc(t) for t in hm3],

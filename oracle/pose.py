@@ -163,6 +163,27 @@ def candidate_weight(p_norm, com, cfg4, hm_j, out_hw=32):
     return f32(hm_j[vv, uu])
 
 
+def exp_f32(x) -> np.float32:
+    """exp(x) for x <= 0 as a FIXED sequence of IEEE fp32 operations: Cody-Waite reduction, the degree-5 polynomial of Cephes expf --
+    the algorithm (and coefficients) of Eigen's pexp<float>, which is the kernel behind tf.exp on the reference's CPU path
+    (hourglass_um_crop_tiny.py:715-721 builds the mean-shift weights with tf.exp) -- every step rounded to fp32, no fused
+    multiply-add.  The HIP vote computes the same sequence (densereg_amd/csrc/vote.h::vote_exp), so the vote is bit-reproducible
+    between the two; against a correctly rounded exp the result is within 1 ulp.  x <= -87 gives 0, NaN propagates."""
+    x = f32(x)
+    if not (x > f32(-87.0)):
+        return x if x != x else f32(0)
+    n = f32(np.rint(f32(x * f32(1.44269504088896341))))
+    r = f32(x - f32(n * f32(0.693359375)))
+    r = f32(r - f32(n * f32(-2.12194440e-4)))
+    q = f32(1.9875691500e-4)
+    for c in (1.3981999507e-3, 8.3334519073e-3, 4.1665795894e-2, 1.6666665459e-1, 5.0000001201e-1):
+        q = f32(f32(q * r) + f32(c))
+    q = f32(f32(q * f32(r * r)) + r)
+    q = f32(q + f32(1.0))
+    s = np.array((int(n) + 127) << 23, np.uint32).view(np.float32)
+    return f32(q * s)
+
+
 def weighted_mean_shift(can: np.ndarray, w: np.ndarray, num_it=MS_ITERS, band_width=MS_BANDWIDTH):
     """hourglass_um_crop_tiny.py:694-724 for one joint. can (n,3), w (n,)."""
     can = can.astype(f32)
@@ -183,7 +204,7 @@ def weighted_mean_shift(can: np.ndarray, w: np.ndarray, num_it=MS_ITERS, band_wi
         for i in range(can.shape[0]):
             d0, d1, d2 = can[i, 0] - c[0], can[i, 1] - c[1], can[i, 2] - c[2]
             s = f32(d0 * d0 + d1 * d1) + d2 * d2
-            s = f32(np.exp(f32(inv_sigma * s))) * w[i]
+            s = exp_f32(f32(inv_sigma * s)) * w[i]
             acc = (acc + can[i] * s).astype(f32)
             ssum = f32(ssum + s)
         if ssum == 0 or not np.isfinite(ssum):

@@ -30,13 +30,13 @@ GRAD_CLIP = 0.2       # train_single_gpu.py:86
 
 
 def loss_and_grads(cfg: NetConfig, params: Dict[str, np.ndarray], dm_norm: np.ndarray, poses: np.ndarray,
-                   cfgs: np.ndarray, coms: np.ndarray, dropout_masks=None, dtype=torch.float32, conv_operands='f32'):
-    """One micro-step. Returns (losses dict, grads dict name->np, bn_updates, end_points np)."""
+                   cfgs: np.ndarray, coms: np.ndarray, dropout_masks=None, dtype=torch.float32, conv_operands='f32', switches=None):
+    """One micro-step. Returns (losses dict, grads dict name->np, bn_updates, end_points np).  ``switches``: oracle/net.py, TorchOps."""
     gt_hm, gt_hm3, gt_um = make_targets(dm_norm, poses, cfgs, coms, cfg.out_hw)
     tp = to_torch_params(params, dtype, requires_grad=True)
     dm = torch.from_numpy(dm_norm).to(dtype)
     masks = None if dropout_masks is None else [torch.from_numpy(m) for m in dropout_masks]
-    ep, ops = detect_net(cfg, tp, dm, True, masks, conv_operands=conv_operands)
+    ep, ops = detect_net(cfg, tp, dm, True, masks, conv_operands=conv_operands, switches=switches)
     tg = lambda a: torch.from_numpy(a).to(dtype)
     l2 = lambda t: (t * t).sum() * 0.5
     hm_loss = sum(l2(e - tg(gt_hm)) for e in ep['hm_outs'])

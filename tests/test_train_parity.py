@@ -843,3 +843,74 @@ def test_ragged_batch_sizes(gpu, B):
     err = np.array([np.abs(g[n] - g64[n]).max() / (np.abs(g64[n]).max() + 1e-12) for n in g64])
     assert err.max() < 6e-2 and np.median(err) < 1e-2
     h.close()
+
+
+def _engine_switches(be, h, cfg, B):
+    """The discrete decisions of the ENGINE's last training forward, as the oracle takes them (oracle/net.py, TorchOps.switches):
+    every ReLU's open units and every stored conv output (for the max-pools' argmax).  A BatchReNorm layer's ReLU is decided by
+    raw * scale + shift > 0 -- the sign of the exact value, which is what the engine's fused multiply-add rounds -- from the layer's
+    raw output and the multiply-add the forward applied (dr_read_activation "<scope>#raw" / "#fold"); a bias layer's by its stored
+    output (no residual add is fused behind a bias layer's ReLU)."""
+    from oracle.graph import conv_specs
+    specs = {c.name: c for c in conv_specs(cfg)}
+
+    def relu(name):
+        c = specs[name]
+        if c.bn:
+            raw = be.read_activation(h, name + '#raw', (B, c.h_out, c.w_out, c.cout)).astype(np.float64)
+            fold = be.read_activation(h, name + '#fold', (2 * c.cout,)).astype(np.float64)
+            return raw * fold[:c.cout] + fold[c.cout:] > 0
+        return be.read_activation(h, name, (B, c.h_out, c.w_out, c.cout)) > 0
+
+    def act(name):
+        c = specs[name]
+        return be.read_activation(h, name, (B, c.h_out, c.w_out, c.cout))
+    return {'relu': relu, 'act': act}
+
+
+def _switch_free_gradient_check(be, cfg, params, ndm, poses, cfgs, coms, bar):
+    """Arithmetic error alone: the engine's fp32 training micro-step against the oracle's fp64 autograd evaluated WITH THE ENGINE'S
+    SWITCHES -- the same ReLU units open, the same max-pool winners (model/hourglass_um_crop_tiny.py:323-371 loss, um_v1.py graph).
+    The bars of _run_step compare two evaluations that each take their own branches: an fp32 network flips a few of its ~10^7 ReLU
+    / max-pool decisions against fp64, and one flip moves a gradient tensor by 1e-3 .. 1e-2 -- which is why those bars cannot be
+    tighter than 6e-2.  With the switches injected nothing discrete is left, and a systematic 1 % error of any tensor (a wrong
+    scale, a missing term, a mis-rounded operand split) would stand two orders of magnitude above the bar."""
+    import torch
+    from oracle import train
+    B = ndm.shape[0]
+    h = be.handle(cfg, B, training=True)
+    h.load_params(params)
+    h.call('dr_finalize_params', be.stream)
+    d_dm, d_pose, d_cfg, d_com, d_lo = be.dev(ndm), be.dev(poses), be.dev(cfgs), be.dev(coms), be.empty((4,))
+    h.call('dr_forward_train', B, be.ptr(d_dm), 0, None, C.c_uint64(0), be.stream)
+    h.call('dr_loss', B, be.ptr(d_dm), be.ptr(d_pose), be.ptr(d_cfg), be.ptr(d_com), be.ptr(d_lo), be.stream)
+    h.call('dr_zero_grad', be.stream)
+    h.call('dr_backward', B, be.stream)
+    be.sync()
+    g = flat_grads_by_name(be, h, cfg)
+    lo64, g64, _, _ = train.loss_and_grads(cfg, params, ndm, poses, cfgs, coms, dtype=torch.float64, switches=_engine_switches(be, h, cfg, B))
+    np.testing.assert_allclose(be.host(d_lo), [lo64[k] for k in ('hm', 'hm3', 'um', 'reg')], rtol=2e-5)
+    names, _, l2, cos = grad_metrics(g, g64)
+    w = int(np.argmax(l2))
+    print('switch-free gradient vs the fp64 oracle, per tensor rel-L2: max %.2e (%s) median %.2e | cosine min %.9f' % (l2.max(), names[w], np.median(l2), cos.min()))
+    # for the record: the same fp64 oracle taking its OWN branches
+    _, g64own, _, _ = train.loss_and_grads(cfg, params, ndm, poses, cfgs, coms, dtype=torch.float64)
+    _, _, l2o, _ = grad_metrics(g, g64own)
+    print('   ... against the fp64 oracle with its own switches: max %.2e median %.2e' % (l2o.max(), np.median(l2o)))
+    assert l2.max() < bar, (l2.max(), names[w])
+    h.close()
+
+
+def test_gradient_without_switches_single_stack(be):
+    """Emulator and GPU: S=1 F=64 J=4, one crop (three on the GPU).  The bar is 1e-4 per tensor (fp32 arithmetic of this depth
+    measures 1e-6 .. 3e-5)."""
+    cfg, params, ndm, poses, cfgs, coms = _case(1, 64, 4, 1 if be.name == 'emu' else 3)
+    _switch_free_gradient_check(be, cfg, params, ndm, poses, cfgs, coms, 1e-4)
+
+
+@pytest.mark.gpu
+def test_gradient_without_switches_config3_b4(gpu):
+    """BASELINE config 3's network (NYU S=2 F=128 J=14) at B=4, the kernels the headline times (x3 family on the big layers): every
+    gradient tensor within 1e-4 relative L2 of the fp64 oracle that takes the engine's branches."""
+    cfg, params, ndm, poses, cfgs, coms = _case(2, 128, 14, 4, 'nyu')
+    _switch_free_gradient_check(gpu, cfg, params, ndm, poses, cfgs, coms, 1e-4)

@@ -26,7 +26,59 @@ struct WgradParams {
     int x_bf16;                                  // conv_wgrad_tr_kernel only: x holds bf16 elements (BnTrainParams::out_bf16)
     int g_bf16;                                  // conv_wgrad_bf16_kernel only: g holds bf16 elements (stride g_cs elements, channel
                                                  // groups of four zero-padded) -- see BnBwdParams::draw_bf16
+    // A layer whose Cin is a multiple of 128 plus a few channels (the comb|uvd inputs of the heads: 515 = 512 + u, v, d; 131 = 128 + 3)
+    // runs as TWO launches into the same slabs: conv_wgrad_x3_kernel<128> on the leading cin_total - tail channels (Cin = that), and
+    // conv_wgrad_tail_kernel on the last ones (ci_base = their first channel).  cin_total = rows of a slab [Cin rows][Cout]; 0 = Cin.
+    int cin_total, ci_base;
 };
+
+// Weight gradient of a FEW input channels (<= 4) of a 1x1 layer: dW[ci][co] = sum_pix x[pix][ci_base + ci] * g[pix][co].  A workgroup
+// = 64 output channels x its slab of pixels; lane = output channel, the four waves take the pixels m = wave (mod 4) (fp32 fma chains
+// in pixel order, the arithmetic class of the fp32-MFMA kernels) and are summed in wave order through LDS: deterministic.  g is
+// streamed once, coalesced (256 B per wave and pixel) -- 0.6 GFLOP and 420 MB for 515 -> 512 at 204 800 pixels: HBM-bound, where the
+// square-tile kernel spent a 128-channel tile (or nine 64-channel ones) on three channels.  Grid = nsplit x ceil(Cout / 64).
+__global__ __launch_bounds__(256) void conv_wgrad_tail_kernel(const WgradParams p) {
+    __shared__ float red[4][4][64];
+    const int split = blockIdx.x % p.nsplit, cblk = blockIdx.x / p.nsplit;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int co = cblk * 64 + lane;
+    const int M = p.B * p.H * p.W;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = m_begin + p.rows_per_split < M ? m_begin + p.rows_per_split : M;
+    const int nt = p.Cin;                                      // tail channels (1..4)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool live = co < p.Cout;
+    const float* gp = p.g + p.g_coff + (live ? co : 0);
+    const float* xp = p.x + p.x_coff + p.ci_base;
+    constexpr int U = 8;                                       // pixels in flight per wave
+    for (int m0 = m_begin + wave; m0 < m_end; m0 += 4 * U) {
+        float gv[U], xv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int mu = m0 + 4 * u;
+            const int m = mu < m_end ? mu : m_begin;
+            gv[u] = gp[(long)m * p.g_cs];
+            bool on = mu < m_end;
+            if (on && p.rowmask) on = !(p.rowmask[m] < p.mask_thresh);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xv[u][k] = (on && k < nt) ? xp[(long)m * p.x_cs + k] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(xv[u][k], gv[u], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[wave][k][lane] = acc[k];
+    __syncthreads();
+    if (wave == 0 && live) {
+        const int ct = p.cin_total ? p.cin_total : p.Cin;
+        float* dst = p.partial + (long)split * ct * p.Cout;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nt) dst[(long)(p.ci_base + k) * p.Cout + co] = ((red[0][k][lane] + red[1][k][lane]) + red[2][k][lane]) + red[3][k][lane];
+    }
+}
 
 // Tile T x T channels, 4 waves as 2 x 2, wave tile T/2 x T/2.
 // T = 128: a wave owns 64 x 64 = 2 x 2 MFMA tiles of 32 contiguous channels each (two dwords per operand and k-step,

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, (T == 128 ? 2 : 4)) void conv_wgrad_x3_kernel(
     if (steps & 1) k_step(0, false);
 
     // partial[split][tap][ci][co]; D: row = (r&3)+8*(r>>2)+4*lk (ci), col = li (co)
-    float* dst = p.partial + ((long)split * taps + tap) * p.Cin * p.Cout;
+    float* dst = p.partial + ((long)split * taps + tap) * (p.cin_total ? p.cin_total : p.Cin) * p.Cout;      // (cin_total: conv_wgrad.h, the tail split)
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int co = co0 + wn * WT + 32 * j + li;

@@ -247,7 +247,7 @@ struct dr_handle {
     // Weight gradients of the full-resolution layers on a library-owned low-priority stream (default; DR_WGRAD_STREAM=0 off): they are
     // needed only by the slab fold at the end of the sweep, so they are queued while the sweep runs the heads of a stack and
     // released when it enters the hourglass below -- a ~1.4 ms chain of launches too small to fill the chip.
-    struct PendingWgrad { dr::WgradParams p; int kind; int grid; };   // kind: 0 <64>, 1 <128>, 2 row kernel, 3 / 4 bf16 <64> / <128>, 16 + id: conv_wgrad16.h
+    struct PendingWgrad { dr::WgradParams p; int kind; int grid; };   // kind: 0 <64>, 1 <128>, 2 row kernel, 3 / 4 bf16 <64> / <128>, 5 conv_wgrad_tail_kernel, 16 + id: conv_wgrad16.h
     std::vector<PendingWgrad> wg_pending;
     hipStream_t wg_stream = nullptr;
     dr::rt::Event wg_ready{}, wg_done{};

@@ -651,6 +651,29 @@ def test_wgrad_x3_against_the_fp32_matrix_cores(be, case):
     assert err[2] < 6 * err[0] + 2e-7, err
 
 
+@pytest.mark.parametrize('case', [(2, 8, 8, 131, 70, 3, True), (1, 9, 7, 259, 300, 5, False), (2, 6, 6, 132, 128, 1, True), (1, 5, 5, 129, 33, 2, False)],
+                         ids=lambda c: 'x'.join(str(int(v)) for v in c))
+def test_wgrad_tail_split_of_a_few_extra_input_channels(be, case):
+    """Cin = a multiple of 128 plus 1..4 channels (the heads' comb|uvd inputs: 515 = 512 + u, v, d; 131): the leading channels on
+    conv_wgrad_x3_kernel<128>, the last ones by conv_wgrad_tail_kernel, both into the same slabs (conv_wgrad.h; T = 129 in the debug
+    entry = the executor's split) -- against the fp64 einsum, masked input rows included, slabs that end inside a pixel step too."""
+    B, H, W, Cin, Cout, nsplit, masked = case
+    rng = np.random.default_rng(sum(case[:5]) + 5)
+    x = (rng.standard_normal((B, H, W, Cin)) * np.exp(rng.uniform(-4, 4, (B, H, W, Cin)))).astype(np.float32)
+    g = (rng.standard_normal((B, H, W, Cout)) * np.exp(rng.uniform(-4, 4, (B, H, W, Cout)))).astype(np.float32)
+    mask = rng.uniform(-1, 1, B * H * W).astype(np.float32) if masked else None
+    xz = x.astype(np.float64)
+    if masked:
+        xz = xz * (~(mask.reshape(B, H, W, 1) < -0.25))
+    ref = np.einsum('bhwc,bhwd->cd', xz, g.astype(np.float64))[None, None]
+    dw = be.wgrad(x, g, 1, 129, nsplit, mask, -0.25)
+    assert dw.shape == (1, 1, Cin, Cout)
+    assert np.abs(dw - ref).max() / np.abs(ref).max() < 2e-5
+    # the tail rows on their own scale too (three channels among hundreds must not hide behind the tensor's maximum)
+    t = Cin - Cin % 128
+    assert np.abs(dw[0, 0, t:] - ref[0, 0, t:]).max() / np.abs(ref[0, 0, t:]).max() < 2e-5
+
+
 def test_wgrad_seeded_shape_sweep(be):
     """A seeded sweep over small random weight-gradient problems -- odd image sides, ragged channel counts, both channel tiles and
     the kernel-row variant, any number of slabs, masked input rows -- against the fp64 einsum of the definition (index math: slab

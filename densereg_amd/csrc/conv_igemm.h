@@ -69,6 +69,7 @@ struct ConvParams {
     int gx, gy;                            // the launch grid (set by the launcher): read with the other arguments instead of from the
                                            // implicit arguments, whose loads sat serialised behind branches in every workgroup's prologue
     int nfast;                             // workgroup -> tile mapping: the N blocks of a row block are consecutive in dispatch order
+    int stagger;                           // conv_x3.h: the second workgroup of every CU in the FIRST round of the grid starts this many s_sleep(127) late (0: off)
     int bf16;                              // w holds bf16 [Kp/32][tap][Np][32] (Kp % 32 == 0): launch the BF kernels
     int x_bf16;                            // BF kernels only: x holds bf16 elements (x_cs / x_coff in elements, channel groups of 4
                                            // zero-padded): a 16-byte slot is loaded as it is, no conversion while staging

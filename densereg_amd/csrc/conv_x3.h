@@ -67,11 +67,19 @@ __host__ __device__ static inline void x3_split4(const float4 v, uint2& h0, uint
 // BD = 1 (two-stage kernels): the weight planes of a K-tile go L2 -> LDS by an LDS-DMA hidden from hipcc (x3_dma.h: inline asm, explicit
 // wait before a raw s_barrier) instead of through registers: no staging registers (the loads were sunk to their ds_write at the 128-register
 // limit), no ds_write_b128, no 64-bit address selects -- the weight path of conv_x3h.h.
-template <int BM, int BN, int LO = 1, int RING = 0, int NW = 4, int WM_ = 2, int BD = 0>
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_kernel(const ConvParams p) {
+// BN = 256 (round 6, the wide 1x1 layers): the pixels of a row block are fetched and split once per 256 output columns instead of once
+// per 128 -- as NW = 8 waves of 64x64 (four accumulator pairs: 256 registers, two waves per SIMD) or NW = 16 waves of 64x32 (the
+// eight-wave kernel's wave, one 1024-thread workgroup per CU).
+template <int BM, int BN, int LO, int NW> constexpr int x3_waves_per_simd() { return NW >= 8 ? (BM * BN / NW > 2048 ? 2 : 4) : LO ? 2 : 3; }
+template <int BM, int BN, int LO = 1, int RING = 0, int NW = 4, int WM_ = 2, int BD = 0, int PF = 0, int ABL_ = 0>
+__global__ __launch_bounds__(NW * 64, (x3_waves_per_simd<BM, BN, LO, NW>())) void conv_x3_kernel(const ConvParams p) {
     static_assert(BD == 0 || RING == 0, "the hidden weight copy belongs to the two-stage loop");
+    static_assert(PF == 0 || BD == 1, "the two-tile pixel prefetch counts its waits by hand: the hidden weight copy only");
+    // PF = 2: the two-stage loop as it is, plus a scheduling barrier between a K-tile's MFMAs and the split of the next tile's pixels: hipcc
+    // otherwise hoists the split (and with it the wait for the global load issued a few instructions earlier) in among the first MFMAs of
+    // every other K-tile -- the wave then sits out the whole HBM round trip with ten of its twelve MFMAs unissued.
     constexpr int NT = NW * 64;                              // threads
-    constexpr int WM = WM_, WN = NW / WM_, WK = 1, MF = 32, ABL = 0;
+    constexpr int WM = WM_, WN = NW / WM_, WK = 1, MF = 32, ABL = ABL_;      // (ABL_ = 3: no epilogue stores -- a measurement build)
     constexpr int kWTM = BM / WM, kWTN = BN / WN, kTM = kWTM / 32, kTN = kWTN / 32;
     static_assert(kWTM % 32 == 0 && kWTN % 32 == 0, "wave tile of whole 32x32 MFMA tiles");
     constexpr int CK = 16;                                   // input channels per K-tile
@@ -107,6 +115,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
     } else if ((gx & 7) == 0) {
         mblk = (blockIdx.x & 7) * (gx >> 3) + (blockIdx.x >> 3);
     }
+    // Co-resident workgroups of equal K run in lock step: all of a round's workgroups reach their epilogues (HBM writes, no MFMA) and the
+    // next round its prologues (HBM latency, no MFMA) together.  Delaying the second workgroup of every CU once, in the first round, by
+    // about half a workgroup's life puts one of a CU's two in its K loop while the other stores / fetches (dispatch is breadth-first: of the
+    // grid's first 512 workgroups, those numbered 32..63 within their XCD are the second on their CU).
+#if !defined(DR_EMU)
+    if (p.stagger > 0) {
+        const unsigned L = blockIdx.y * gridDim.x + blockIdx.x;
+        const int n = p.stagger & 0xFFFF, mode = p.stagger >> 16;
+        bool late;
+        if (mode == 0) late = ((L >> 3) >> 5) & 1u;                        // breadth-first dispatch: the XCD's workgroups 32..63
+        else if (mode == 1) late = (L >> 3) & 1u;                          // depth-first: every other workgroup of an XCD
+        else late = (__builtin_amdgcn_s_getreg(6148) & 15u) >= 2u;         // HW_ID.wave_id: this wave's slot on its SIMD (the first workgroup of a CU holds 0, 1)
+        if (L < 512u && late)
+            for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int m0 = mblk * BM;
     const int n0 = nblk * BN;
     const int taps = p.ksize * p.ksize;
@@ -158,14 +182,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
     }
     const long w_tile = 3l * p.Np * 16;                                    // bf16 elements per (chunk, tap)
 
-    float4 a_reg[kAIters];
+    float4 a_reg[kAIters], a_reg2[PF ? kAIters : 1];                       // (PF: a second set -- the pixels of two K-tiles in flight)
     float4 b_reg0, b_reg1, b_reg2;                                          // (scalars: hipcc keeps a float4[3] refilled inside the unrolled K loop in scratch)
     static_assert(kBIters <= 3, "weight loader mapping");
     int ld_kc = 0, ld_dy = -pad, ld_dx = -pad, ld_tap = 0;
     const float* ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;
     const __bf16* ld_w = w3;
-    int a_nv[kAIters];
-    auto load_tile = [&]() __attribute__((always_inline)) {
+    int a_nv[kAIters], a_nv2[PF ? kAIters : 1];
+    auto load_tile_to = [&](float4 (&a_reg)[kAIters], int (&a_nv)[kAIters]) __attribute__((always_inline)) {
         const bool tail = ld_kc + CK > p.Cin;                              // uniform: this chunk crosses Cin
 #pragma unroll
         for (int i = 0; i < kAIters; ++i) {
@@ -196,8 +220,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
         ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;
         ld_w += w_tile;
     };
+    auto load_tile = [&]() __attribute__((always_inline)) { load_tile_to(a_reg, a_nv); };
     const bool ragged = (p.Cin & 3) != 0;
-    auto store_tile = [&](const int buf, const bool was_tail) __attribute__((always_inline)) {
+    auto store_tile_from = [&](const int buf, const bool was_tail, const float4 (&a_reg)[kAIters], const int (&a_nv)[kAIters]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < kAIters; ++i) {
             const int r = a_row[i], q = a_q[i];
@@ -224,6 +249,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
             if constexpr (kBIters > 2) { if (kBUnits % NT == 0 || tid + 2 * NT < kBUnits) bs[b_lds[2]] = b_reg2; }
         }
     };
+    auto store_tile = [&](const int buf, const bool was_tail) __attribute__((always_inline)) { store_tile_from(buf, was_tail, a_reg, a_nv); };
     // RING: the weight planes of a K-tile go HBM / L2 -> LDS without registers (global_load_lds_dwordx4): wave w copies the 64-unit
     // chunks w, w + 4, ... of the tile's 3 * BN * 2 units; the LDS image is lane-linear, so the slot swizzle moves to the SOURCE
     // address (unit L = (plane, row, physical slot) fetches logical slot = physical ^ ((row >> 3) & 1)).
@@ -343,6 +369,51 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
             ring_tile(0, 1, 2, false, false, false);
         }
         __syncthreads();                                                    // (the epilogue reuses stage 0 as scratch)
+    } else if constexpr (PF == 1) {
+    // ---- two stages, the pixels of TWO K-tiles in flight (the short-K 1x1 layers: eight K-tiles behind one prologue; a K-tile's MFMAs
+    // last a third of an HBM round trip).  Tile t (stage t & 1): weight copy of t+1 | pixel loads of t+2 into register set t & 1 (free:
+    // tile t's pixels went to LDS a tile ago) | the MFMAs of t | split + ds_write the pixels of t+1 from the other set | wait until only
+    // the loads of t+2 are outstanding (loads return in order: the copy of t+1, issued BEFORE them, has landed) | barrier.
+#if defined(DR_EMU)
+#define X3_WAIT_BUT_PIXELS() ((void)0)
+#else
+#define X3_WAIT_BUT_PIXELS() do { if constexpr (kAIters == 1) P3_WAIT_VM(1); else if constexpr (kAIters == 2) P3_WAIT_VM(2); else P3_WAIT_VM(0); } while (0)
+#endif
+    dma_bd(0);
+    load_tile_to(a_reg, a_nv);
+    bool tl2 = false;
+    if (T_total > 1) { tl2 = ld_kc + CK > p.Cin; load_tile_to(a_reg2, a_nv2); }
+    if (T_total > 1) X3_WAIT_BUT_PIXELS(); else P3_WAIT_VM(0);            // the weight copy and the pixels of tile 0 (tile 1's stay in flight)
+    store_tile_from(0, tail0, a_reg, a_nv);
+    if (T_total > 1) X3_WAIT_BUT_PIXELS(); else P3_WAIT_VM(0);            // (its lgkmcnt(0): the ds_writes)
+    __builtin_amdgcn_s_barrier();
+    bool tl1 = false;
+    auto pf_tile = [&](const int buf, const bool more1, const bool more2, float4 (&rl)[kAIters], int (&nvl)[kAIters], bool& tl_l,
+                       const float4 (&rs)[kAIters], const int (&nvs)[kAIters], const bool tl_s) __attribute__((always_inline)) {
+        if (more1) dma_bd(buf ^ 1);
+        if (more2) { tl_l = ld_kc + CK > p.Cin; load_tile_to(rl, nvl); }
+        float4 a0[kTM], b0[kTN], ax[kTM], bx[kTN];
+        X3_READ_A(a0, 0, buf); X3_READ_B(b0, 0, buf); X3_READ_A(ax, 2, buf); X3_READ_B(bx, 2, buf);
+        X3_MMA(LOACC, ax, b0);
+        X3_MMA(LOACC, a0, bx);
+        X3_READ_A(ax, 1, buf); X3_READ_B(bx, 1, buf);
+        X3_MMA(acc, a0, b0);
+        X3_MMA(LOACC, ax, b0);
+        X3_MMA(LOACC, a0, bx);
+        X3_MMA(LOACC, ax, bx);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more1) store_tile_from(buf ^ 1, tl_s, rs, nvs);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) X3_WAIT_BUT_PIXELS(); else P3_WAIT_VM(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    const int T_pairs = T_total & ~1;
+    for (int t = 0; t < T_pairs; t += 2) {
+        pf_tile(0, true, t + 2 < T_total, a_reg, a_nv, tl1, a_reg2, a_nv2, tl2);
+        pf_tile(1, t + 2 < T_total, t + 3 < T_total, a_reg2, a_nv2, tl2, a_reg, a_nv, tl1);
+    }
+    if (T_total & 1) pf_tile(0, false, false, a_reg, a_nv, tl1, a_reg2, a_nv2, tl2);
+#undef X3_WAIT_BUT_PIXELS
     } else {
     load_tile(); dma_bd(0);
     store_tile(0, tail0);
@@ -361,6 +432,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
         X3_MMA(LOACC, ax, b0);                                                // a1*b0   (the corrections in the ring's order: same bits)
         X3_MMA(LOACC, a0, bx);                                                // a0*b1
         X3_MMA(LOACC, ax, bx);                                                // a1*b1
+        if constexpr (PF == 2) __builtin_amdgcn_sched_barrier(0);
         if (more) store_tile(buf ^ 1, was_tail);
         if constexpr (BD) {                                                 // the tile's MFMAs are issued, then: the copy has landed, every LDS access returned
             __builtin_amdgcn_sched_barrier(0);
@@ -393,7 +465,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
 #if !defined(DR_X3_EPB)
 #define DR_X3_EPB 4                                          // (A/B builds: 8)
 #endif
-    constexpr int EP_BATCH_ROWS = NW == 8 ? DR_X3_EPB : 8;  // (eight waves live on 128 registers: four rows of epilogue loads in flight)
+    constexpr int EP_BATCH_ROWS = x3_waves_per_simd<BM, BN, LO, NW>() == 4 ? DR_X3_EPB : 8;  // (four waves per SIMD live on 128 registers: four rows of epilogue loads in flight)
     constexpr int EP_TS = MF, EP_NR = NR;
     const int ep_lg = lk, ep_lc = li;
     {
@@ -415,12 +487,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : LO ? 2 : 3)) void conv_x3_k
             }
         }
         __syncthreads();
-        for (int e = tid; e < 2 * BN; e += NT) {
-            const int which = e / BN, col = e % BN, n = n0 + col;
+        // one partial row per 128 pixel rows whatever BM (BM = 256: two rows per workgroup, each the sum of its two 64-row waves -- the
+        // rows, and the bits, of the 128-row kernel)
+        constexpr int kHalves = BM / 128, kWH = WM / kHalves;
+        static_assert(BM % 128 == 0 && WM % kHalves == 0, "statistics rows are 128 pixel rows");
+        const int srows = (M + 127) >> 7;
+        for (int e = tid; e < 2 * BN * kHalves; e += NT) {
+            const int half = e / (2 * BN), which = (e / BN) % 2, col = e % BN, n = n0 + col;
             double t = 0.0;
 #pragma unroll
-            for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + col];
-            if (n < p.Cout) p.stat_part[((long)which * p.Cout + n) * gx + mblk] = t;
+            for (int w = 0; w < kWH; ++w) t += red[(which * WM + half * kWH + w) * BN + col];
+            const int srow = mblk * kHalves + half;
+            if (n < p.Cout && srow < srows) p.stat_part[((long)which * p.Cout + n) * srows + srow] = t;
         }
     }
     (void)wk; (void)WK;

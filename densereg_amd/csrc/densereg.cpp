@@ -180,6 +180,17 @@ static bool x3_bd() {
     static const bool on = [] { const char* e = getenv("DR_X3_BD"); return !(e && e[0] == '0'); }();
     return on;
 }
+// ... and the pixels of two K-tiles in flight (conv_x3.h, PF = 1) or a scheduling barrier before the split (PF = 2).  DR_X3_PF = mode
+// (0 off), DR_X3_PF_MAXT = n: only layers of at most n K-tiles (1x1: Cin <= 16 n)
+[[maybe_unused]] static bool x3_abl3() {
+    static const bool on = [] { const char* e = getenv("DR_X3_ABL"); return e && atoi(e) == 3; }();
+    return on;
+}
+[[maybe_unused]] static int x3_pf(const ConvParams& p) {
+    static const int mode = [] { const char* e = getenv("DR_X3_PF"); return e ? atoi(e) : 0; }();
+    static const int lim = [] { const char* e = getenv("DR_X3_PF_MAXT"); return e ? atoi(e) : 1 << 30; }();
+    return p.ksize * p.ksize * (p.Kp / 16) <= lim ? mode : 0;
+}
 bool conv_use_x3(const ConvParams& p) {
     static const int env = [] { const char* e = getenv("DR_CONV_X3"); return e ? atoi(e) : 1; }();
     const int mode = g_dbg_x3 >= 0 ? g_dbg_x3 : env;
@@ -191,7 +202,6 @@ bool conv_use_x3(const ConvParams& p) {
     const int ncols = p.Ng > 0 ? p.Ng : p.Np;
     // whole 128-column blocks (a 160-column layer would compute 256), and a grid of at least two workgroups per CU
     static const long min_wgs = [] { const char* e = getenv("DR_X3_MIN_WGS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 512l; }();
-    if (ncols % 128 == 0) return dr_ceil_div((int)M, 128) * (long)(ncols / 128) >= min_wgs && (long)p.ksize * p.ksize * p.Kp >= 128;
     // 64-column blocks (the hourglass bottlenecks' 64 channels) on deep grids: 3x3 64->64 at 204 800 rows 165 -> 126 us, 1x1 128->64
     // 48.5 -> 43.6 (profiles/r05_x3_microbench.md); DR_X3_BN64=0 off
     static const bool bn64 = [] { const char* e = getenv("DR_X3_BN64"); return !(e && e[0] == '0'); }();
@@ -207,6 +217,9 @@ bool conv_use_x3(const ConvParams& p) {
         if (ncols % 64 == 0) return bn64 && rb * (ncols / 64) >= 256;
         return false;
     }
+    // (the halo rule first: round 6 shipped it BEHIND the 128-column rule below, which turned away the 3x3 128 -> 128 layers of a 40-crop
+    // batch -- 320 workgroups -- that the halo rule was measured for: 116 us on the fp32 tile)
+    if (ncols % 128 == 0) return dr_ceil_div((int)M, 128) * (long)(ncols / 128) >= min_wgs && (long)p.ksize * p.ksize * p.Kp >= 128;
     if (ncols == 96) return bn96 && dr_ceil_div((int)M, 128) >= 2 * min_wgs && (long)p.ksize * p.ksize * p.Kp >= 128;
     return bn64 && ncols % 64 == 0 && dr_ceil_div((int)M, 128) * (long)(ncols / 64) >= 2 * min_wgs && (long)p.ksize * p.ksize * p.Kp >= 128;
 }
@@ -269,7 +282,23 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         const int ncols = p.Ng > 0 ? p.Ng : p.Np;
         const bool bn96 = ncols == 96;                                       // the 65..96-channel layers: one 96-column block
         const bool bn64 = !bn96 && ncols % 128 != 0 && ncols % 64 == 0;      // 64-column blocks where 128 would compute padding
-        dim3 grid(dr_ceil_div((int)M, 128), bn96 ? 1 : dr_ceil_div(ncols, bn64 ? 64 : 128));
+        {   // DR_X3_STAGGER = k: second workgroups of the first round start (K-tiles * k / 16) x s_sleep(127) late (conv_x3.h)
+            static const int stag = [] { const char* e = getenv("DR_X3_STAGGER"); return e ? atoi(e) : 0; }();
+            const int T_total = p.ksize * p.ksize * (p.Kp / 16);
+            static const int stag_mode = [] { const char* e = getenv("DR_X3_STAGGER_MODE"); return e ? atoi(e) : 0; }();
+            q.stagger = stag > 0 ? (std::max(1, (T_total * stag + 8) / 16) | (stag_mode << 16)) : 0;
+        }
+        // larger blocks for the wide layers the halo kernel does not take (DR_X3_BIG: 0 off; 256-column blocks: 1 eight waves of 64x64,
+        // 2 sixteen of 64x32; 256-ROW blocks (the weight tile fetched once per 256 pixels): 3 eight waves of 64x64, 4 sixteen of 64x32)
+#if defined(DR_DEBUG_HOOKS)
+        static const int big_mode = [] { const char* e = getenv("DR_X3_BIG"); return e ? atoi(e) : 0; }();
+#else
+        constexpr int big_mode = 0;                                          // (measured equal or slower, profiles/r06_experiments.md: test / bench library only)
+#endif
+        const bool big_ok = big_mode > 0 && variant == 0 && (g_dbg_x3 < 3 || g_dbg_x3 == 7) && !conv_x3h_shape(p);
+        const bool bn256 = big_ok && big_mode <= 2 && ncols % 256 == 0;
+        const bool bm256 = big_ok && big_mode >= 3 && ncols % 128 == 0 && (p.grp_rows <= 0 || p.grp_rows % 256 == 0);
+        dim3 grid(dr_ceil_div((int)M, bm256 ? 256 : 128), bn96 ? 1 : dr_ceil_div(ncols, bn64 ? 64 : bn256 ? 256 : 128));
         q.gx = (int)grid.x; q.gy = (int)grid.y;
         // variants (DR_X3_VARIANT bit 0: one accumulator, bit 1: three-stage LDS ring, bit 2: four waves of 64x64 instead of eight of 64x32;
         // dr_dbg_force_x3 3 / 4 / 5 select the same)
@@ -294,6 +323,15 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
             ++g_x3h_launches;
             return 0;
         }
+#if defined(DR_DEBUG_HOOKS)
+        if (bn256) {
+            if (big_mode == 2) DR_LAUNCH((conv_x3_kernel<128, 256, 1, 0, 16, 2, 1>), grid, dim3(1024), 0, s, q);
+            else DR_LAUNCH((conv_x3_kernel<128, 256, 1, 0, 8, 2, 1>), grid, dim3(512), 0, s, q);
+        } else if (bm256) {
+            if (big_mode == 4) DR_LAUNCH((conv_x3_kernel<256, 128, 1, 0, 16, 4, 1>), grid, dim3(1024), 0, s, q);
+            else DR_LAUNCH((conv_x3_kernel<256, 128, 1, 0, 8, 4, 1>), grid, dim3(512), 0, s, q);
+        } else
+#endif
         if (bn96) {
             DR_LAUNCH((conv_x3_kernel<128, 96, 1, 0, 4, 4>), grid, dim3(256), 0, s, q);
         } else if (bn64) {
@@ -308,6 +346,11 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
             else if (ring) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 1>), grid, dim3(256), 0, s, q);
 #endif
             else if (w4) DR_LAUNCH((conv_x3_kernel<128, 128, 1>), grid, dim3(256), 0, s, q);
+#if defined(DR_DEBUG_HOOKS)
+            else if (x3_bd() && x3_abl3()) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1, 0, 3>), grid, dim3(512), 0, s, q);
+            else if (x3_bd() && x3_pf(p) == 1) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1, 1>), grid, dim3(512), 0, s, q);
+            else if (x3_bd() && x3_pf(p) == 2) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1, 2>), grid, dim3(512), 0, s, q);
+#endif
             else if (x3_bd()) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1>), grid, dim3(512), 0, s, q);
             else DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8>), grid, dim3(512), 0, s, q);
         }

@@ -505,11 +505,11 @@ __global__ __launch_bounds__(256) void wgrad_fold_all_kernel(const float* slabs,
         for (; k + 7 * 4 < sg.nsplit; k += 8 * 4) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = part[(long)(k + u * 4) * sg.n + i];
+            for (int u = 0; u < 8; ++u) v[u] = DR_NT_LOAD(8, &part[(long)(k + u * 4) * sg.n + i]);
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; k < sg.nsplit; k += 4) s += part[(long)k * sg.n + i];
+        for (; k < sg.nsplit; k += 4) s += DR_NT_LOAD(8, &part[(long)k * sg.n + i]);
     }
     red[sl][e] = s;
     __syncthreads();

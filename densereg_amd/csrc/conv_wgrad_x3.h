@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, (T == 128 ? 2 : 4)) void conv_wgrad_x3_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
                 const int ci = ci0 + wm * WT + 32 * i + row;
-                if (ci < p.Cin && co < p.Cout) dst[(long)ci * p.Cout + co] = acc[i][j][r] + lo[i][j][r];
+                if (ci < p.Cin && co < p.Cout) DR_NT_STORE(16, &dst[(long)ci * p.Cout + co], acc[i][j][r] + lo[i][j][r]);
             }
     }
 #undef DR_XS

@@ -257,6 +257,19 @@ typedef float dr_f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 dr_bf16x8 __attribute__((ext_vector_type(8)));      // one operand of v_mfma_f32_32x32x16_bf16
 typedef __bf16 dr_bf16x4 __attribute__((ext_vector_type(4)));
 typedef float dr_f32x4 __attribute__((ext_vector_type(4)));
+// DR_NT (experiment switch of the build, bit mask): non-temporal hints on streams that are written once and read once --
+//   4 the conv epilogues' output stores, 8 the fold launch's slab loads, 16 the weight-gradient kernels' slab stores
+// (the BatchReNorm passes have their own: DR_BN_NT, train_kernels.h)
+#ifndef DR_NT
+#define DR_NT 0
+#endif
+#if defined(DR_EMU)
+#define DR_NT_STORE(bit, ptr, v) (*(ptr) = (v))
+#define DR_NT_LOAD(bit, ptr) (*(ptr))
+#else
+#define DR_NT_STORE(bit, ptr, v) do { if constexpr ((DR_NT & (bit)) != 0) __builtin_nontemporal_store((v), (ptr)); else *(ptr) = (v); } while (0)
+#define DR_NT_LOAD(bit, ptr) (((DR_NT & (bit)) != 0) ? __builtin_nontemporal_load(ptr) : *(ptr))
+#endif
 
 __host__ __device__ static inline int dr_ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ static inline int dr_round_up(int a, int b) { return dr_ceil_div(a, b) * b; }

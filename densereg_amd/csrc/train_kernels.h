@@ -107,6 +107,26 @@ template <int R16> struct BnRows { static constexpr int value = R16 ? DR_BN_ROWS
 // the bf16 path -- half the bytes of the tensor every BatchReNorm pass reads.  A COMPILE-TIME variant of the streaming kernels:
 // as a run-time branch around the loads it kept hipcc from issuing a thread's loads as one batch (measured: the backward reduce
 // pass 4.8 -> 7.9 ms per three windows with HALF the raw bytes; profiles/r04_experiments.md section 9).
+// DR_BN_NT (experiment switch of the build): bit 1 = the passes' 16-byte stores non-temporal, bit 2 = their 16-byte fp32 loads
+#ifndef DR_BN_NT
+#define DR_BN_NT 3                        // (measured, visit 24: stores +0.25 %, loads +0.5 %, both +0.9-1.4 % on the step)
+#endif
+__device__ __forceinline__ float4 bn_ld4(const float* p) {
+#if (DR_BN_NT & 2) && !defined(DR_EMU)
+    const dr_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const dr_f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void bn_st4(float* p, const float4 v) {
+#if (DR_BN_NT & 1) && !defined(DR_EMU)
+    const dr_f32x4 f = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(f, reinterpret_cast<dr_f32x4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
 template <int R16>
 __device__ __forceinline__ float4 bn_load_raw4(const float* raw, long e) {
     if (R16) {
@@ -114,7 +134,7 @@ __device__ __forceinline__ float4 bn_load_raw4(const float* raw, long e) {
         const dr_f32x4 f = __builtin_convertvector(h, dr_f32x4);
         return make_float4(f[0], f[1], f[2], f[3]);
     }
-    return *reinterpret_cast<const float4*>(raw + e);
+    return bn_ld4(raw + e);
 }
 template <int R16>
 __device__ __forceinline__ const float* bn_raw_advance(const float* raw, long elems) {
@@ -425,7 +445,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
 #pragma unroll
             for (int u = 0; u < kRows; ++u) {
                 const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
-                rv[u] = *reinterpret_cast<const float4*>(p.res.p + mc * p.res.cs + p.res.coff + cg * 4);
+                rv[u] = bn_ld4(p.res.p + mc * p.res.cs + p.res.coff + cg * 4);
             }
         }
 #pragma unroll
@@ -450,7 +470,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
                 const dr_f32x4 f = {cg * 4 + 0 < p.C ? v[0] : 0.f, cg * 4 + 1 < p.C ? v[1] : 0.f, cg * 4 + 2 < p.C ? v[2] : 0.f, cg * 4 + 3 < p.C ? v[3] : 0.f};
                 *reinterpret_cast<dr_bf16x4*>(reinterpret_cast<__bf16*>(p.out.p) + m * p.out.cs + p.out.coff + cg * 4) = __builtin_convertvector(f, dr_bf16x4);
             } else if (vec_out) {
-                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                bn_st4(o, make_float4(v[0], v[1], v[2], v[3]));
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -532,7 +552,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p_
 #pragma unroll
                 for (int u = 0; u < kRows; ++u) {
                     const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
-                    d4[u] = *reinterpret_cast<const float4*>(p.dout.p + mc * p.dout.cs + p.dout.coff + cg * 4);
+                    d4[u] = bn_ld4(p.dout.p + mc * p.dout.cs + p.dout.coff + cg * 4);
                 }
             }
 #pragma unroll
@@ -715,7 +735,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_i
 #pragma unroll
             for (int u = 0; u < kRows; ++u) {
                 const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
-                d4[u] = *reinterpret_cast<const float4*>(p.dout.p + mc * p.dout.cs + p.dout.coff + cg * 4);
+                d4[u] = bn_ld4(p.dout.p + mc * p.dout.cs + p.dout.coff + cg * 4);
             }
         }
         const bool acc_r = vec_r && p.dres_acc;                       // the residual gradient this pass adds to: same batch of loads
@@ -723,7 +743,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_i
 #pragma unroll
             for (int u = 0; u < kRows; ++u) {
                 const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
-                r4[u] = *reinterpret_cast<const float4*>(p.dres.p + mc * p.dres.cs + p.dres.coff + cg * 4);
+                r4[u] = bn_ld4(p.dres.p + mc * p.dres.cs + p.dres.coff + cg * 4);
             }
         }
 #pragma unroll
@@ -745,7 +765,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_i
                 if (vec_r) {
                     float4 v = make_float4(g[0], g[1], g[2], g[3]);
                     if (acc_r) { v.x += r4[u].x; v.y += r4[u].y; v.z += r4[u].z; v.w += r4[u].w; }
-                    *reinterpret_cast<float4*>(q) = v;
+                    bn_st4(q, v);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
@@ -763,7 +783,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_i
                 const dr_f32x4 f = {o[0], o[1], o[2], o[3]};
                 *reinterpret_cast<dr_bf16x4*>(reinterpret_cast<__bf16*>(p.draw) + m * p.raw_cs + cg * 4) = __builtin_convertvector(f, dr_bf16x4);
             } else {
-                *reinterpret_cast<float4*>(p.draw + m * p.raw_cs + cg * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                bn_st4(p.draw + m * p.raw_cs + cg * 4, make_float4(o[0], o[1], o[2], o[3]));
             }
         }
     }

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NW * 64, (x3_waves_per_simd<BM, BN, LO, NW>())) voi
 
     float4 a_reg[kAIters], a_reg2[PF ? kAIters : 1];                       // (PF: a second set -- the pixels of two K-tiles in flight)
     float4 b_reg0, b_reg1, b_reg2;                                          // (scalars: hipcc keeps a float4[3] refilled inside the unrolled K loop in scratch)
-    static_assert(kBIters <= 3, "weight loader mapping");
+    static_assert(BD || kBIters <= 3, "weight loader mapping");
     int ld_kc = 0, ld_dy = -pad, ld_dx = -pad, ld_tap = 0;
     const float* ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;
     const __bf16* ld_w = w3;
@@ -275,13 +275,14 @@ __global__ __launch_bounds__(NW * 64, (x3_waves_per_simd<BM, BN, LO, NW>())) voi
     // BD: wave w issues the 1 KB copies 3 w .. 3 w + 2 of a stage's kBUnits / 64 (lane L of copy q = unit 64 q + L = (plane, row, physical
     // slot), fetching the logical slot; rows beyond Np read zeros: x3_dma.h)
     constexpr int kBInstr = kBUnits / 64;
-    static_assert(!BD || (kBUnits % 64 == 0 && kBInstr <= 3 * NW), "weight copies");
+    constexpr int kBQ = (kBInstr + NW - 1) / NW > 3 ? (kBInstr + NW - 1) / NW : 3;      // copies per wave (three; four for the 160-column tile's 15 over four waves)
+    static_assert(!BD || (kBUnits % 64 == 0 && kBInstr <= kBQ * NW), "weight copies");
     const P3Src srcB = p3_src(p.w3, 0, BD ? (size_t)T_total * p.Np * 96 : 0);
-    unsigned bq_voff[3];
-    const int bq_n = !BD ? 0 : kBInstr - wave * 3 < 0 ? 0 : (kBInstr - wave * 3 > 3 ? 3 : kBInstr - wave * 3);
+    unsigned bq_voff[kBQ];
+    const int bq_n = !BD ? 0 : kBInstr - wave * kBQ < 0 ? 0 : (kBInstr - wave * kBQ > kBQ ? kBQ : kBInstr - wave * kBQ);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int u = (wave * 3 + j) * 64 + lane;
+    for (int j = 0; j < kBQ; ++j) {
+        const int u = (wave * kBQ + j) * 64 + lane;
         const int pl = u / (BN * 2), within = u % (BN * 2), row = within >> 1, ls = (within & 1) ^ ((row >> 3) & 1);
         bq_voff[j] = (BD && u < kBUnits && n0 + row < p.Np) ? (unsigned)(((n0 + row) * 3 + pl) * 32 + ls * 16) : kP3Oob;
     }
@@ -289,8 +290,8 @@ __global__ __launch_bounds__(NW * 64, (x3_waves_per_simd<BM, BN, LO, NW>())) voi
     auto dma_bd = [&](const int st) __attribute__((always_inline)) {
         if constexpr (!BD) return;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            if (j < bq_n) p3_dma16(srcB, bq_voff[j], bq_soff, reinterpret_cast<unsigned char*>(&DR_BS(st)[0][0][0]), (unsigned)((wave * 3 + j) * 1024));
+        for (int j = 0; j < kBQ; ++j)
+            if (j < bq_n) p3_dma16(srcB, bq_voff[j], bq_soff, reinterpret_cast<unsigned char*>(&DR_BS(st)[0][0][0]), (unsigned)((wave * kBQ + j) * 1024));
         bq_soff += (unsigned)p.Np * 96u;
     };
 

@@ -210,6 +210,10 @@ bool conv_use_x3(const ConvParams& p) {
     static const bool bn96 = [] { const char* e = getenv("DR_X3_BN96"); return !(e && e[0] == '0'); }();
     // the halo kernel wins from one workgroup per CU on (profiles/r06_x3h_rule.md: at 320 row blocks 1.38-1.85x the fp32 tiles, at 400 row
     // blocks of 16x16 pixels 1.7-1.9x, at 80 equal): inference at B = 40 and the 16x16 level of a 200-crop window included
+    // one 160-column block for the 129..160-channel layers (the input gradients of the 131 / 156-channel 1x1 layers; config 5's 129 / 142-
+    // channel 3x3 layers) on deep grids, in place of the fp32 16-column tiles; DR_X3_BN160=0 off
+    static const bool bn160 = [] { const char* e = getenv("DR_X3_BN160"); return !(e && e[0] == '0'); }();
+    if (ncols == 160) return bn160 && dr_ceil_div((int)M, 128) >= 2 * min_wgs && (long)p.ksize * p.ksize * p.Kp >= 128;
     if (conv_x3h_shape(p) && p.Kp >= 64) {
         const long rb = dr_ceil_div((int)M, 128);
         if (ncols % 128 == 0) return rb * (ncols / 128) >= 256;
@@ -281,7 +285,8 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         q.nfast = nfast;
         const int ncols = p.Ng > 0 ? p.Ng : p.Np;
         const bool bn96 = ncols == 96;                                       // the 65..96-channel layers: one 96-column block
-        const bool bn64 = !bn96 && ncols % 128 != 0 && ncols % 64 == 0;      // 64-column blocks where 128 would compute padding
+        const bool bn160 = ncols == 160;                                     // the 129..160-channel layers: one 160-column block
+        const bool bn64 = !bn96 && !bn160 && ncols % 128 != 0 && ncols % 64 == 0;      // 64-column blocks where 128 would compute padding
         {   // DR_X3_STAGGER = k: second workgroups of the first round start (K-tiles * k / 16) x s_sleep(127) late (conv_x3.h)
             static const int stag = [] { const char* e = getenv("DR_X3_STAGGER"); return e ? atoi(e) : 0; }();
             const int T_total = p.ksize * p.ksize * (p.Kp / 16);
@@ -298,7 +303,7 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         const bool big_ok = big_mode > 0 && variant == 0 && (g_dbg_x3 < 3 || g_dbg_x3 == 7) && !conv_x3h_shape(p);
         const bool bn256 = big_ok && big_mode <= 2 && ncols % 256 == 0;
         const bool bm256 = big_ok && big_mode >= 3 && ncols % 128 == 0 && (p.grp_rows <= 0 || p.grp_rows % 256 == 0);
-        dim3 grid(dr_ceil_div((int)M, bm256 ? 256 : 128), bn96 ? 1 : dr_ceil_div(ncols, bn64 ? 64 : bn256 ? 256 : 128));
+        dim3 grid(dr_ceil_div((int)M, bm256 ? 256 : 128), (bn96 || bn160) ? 1 : dr_ceil_div(ncols, bn64 ? 64 : bn256 ? 256 : 128));
         q.gx = (int)grid.x; q.gy = (int)grid.y;
         // variants (DR_X3_VARIANT bit 0: one accumulator, bit 1: three-stage LDS ring, bit 2: four waves of 64x64 instead of eight of 64x32;
         // dr_dbg_force_x3 3 / 4 / 5 select the same)
@@ -309,6 +314,10 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
         const bool ring = false;
 #endif
         const bool w4 = (variant & 4) || g_dbg_x3 == 5 || one_acc || ring;
+        if (bn160) {                                                         // (no halo form, no variants)
+            DR_LAUNCH((conv_x3_kernel<128, 160, 1, 0, 4, 4, 1>), grid, dim3(256), 0, s, q);
+            return 0;
+        }
         if (conv_x3h_shape(p) && !one_acc && !ring && !w4) {
             if (bn96) {
                 if (p.W == 32) DR_LAUNCH((conv_x3h_kernel<96, 5, 4, 4>), grid, dim3(256), 0, s, q);

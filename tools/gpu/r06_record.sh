@@ -27,9 +27,10 @@ rm -rf $G/pmc_*_fetch $G/pmc_*_write                       # (the databases are 
 # ---- bench lines -------------------------------------------------------------------------------------------------------------------
 timeout 400 python bench.py --detail $G/r06_detail_train.md > $G/r06_bench_train.json 2> $G/r06_bench_train.err; echo "bench rc=$?" >> $G/r06_bench_train.err
 timeout 300 python bench.py --mode infer --detail $G/r06_detail_infer.md > $G/r06_bench_infer.json 2> $G/r06_bench_infer.err
+timeout 300 python bench.py --mode infer --replicas 1 --merge 1 --steps 100 --warmup 10 --no-cpu-baseline --detail $G/r06_detail_infer_b40.md > $G/r06_bench_infer_b40.json 2> $G/r06_bench_infer_b40.err   # one engine, one 40-crop batch per launch: config 2 as stated
 Q="--no-cpu-baseline --steps 40 --warmup 10"
 DR_CONV_X3=0 timeout 200 python bench.py $Q --no-forward-vote --detail $G/r06_detail_train_x3off.md > $G/r06_bench_train_x3off.json 2> $G/r06_bench_train_x3off.err   # the fp32 matrix cores only (round 4's kernels), same box
-DR_X3_HALO=0 DR_X3_BD=0 DR_WG_TAIL=0 timeout 200 python bench.py $Q --no-forward-vote --detail $G/r06_detail_train_r05kernels.md > $G/r06_bench_train_r05kernels.json 2> $G/r06_bench_train_r05kernels.err   # round 5's kernel selection (no halo kernel, register-staged weights, no tail split), same box
+DR_X3_HALO=0 DR_X3_BD=0 DR_WG_TAIL=0 DR_X3_BN160=0 timeout 200 python bench.py $Q --no-forward-vote --detail $G/r06_detail_train_r05kernels.md > $G/r06_bench_train_r05kernels.json 2> $G/r06_bench_train_r05kernels.err   # round 5's kernel selection (no halo kernel, register-staged weights, no tail split, no 160-column tile; the BatchReNorm passes keep their non-temporal hints: a compile-time switch), same box
 timeout 200 python bench.py $Q --groups 1 --no-forward-vote --no-profile > $G/r06_bench_train_g1.json 2> $G/r06_bench_train_g1.err      # one micro-step per pass, two in flight
 timeout 200 python bench.py --dataset msra $Q > $G/r06_bench_msra.json 2> $G/r06_bench_msra.err
 timeout 200 python bench.py --precision bf16 $Q > $G/r06_bench_train_bf16.json 2> $G/r06_bench_train_bf16.err
@@ -49,7 +50,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/$G/prof_infer -o infer -- pyt
 cd $R
 for n in train train_inline infer; do
   db=$(ls $G/prof_$n/*_results.db 2>/dev/null | head -1)
-  [ -n "$db" ] && python tools/rocpd_summary.py $db "bench.py (round 6, $n)" > $G/r06_${n}_kernel_stats.md && rm -rf $G/prof_$n
+  [ -n "$db" ] && python tools/rocpd_summary.py $db "bench.py (round 6, $n)" > $G/r06_${n}_kernel_stats.md && python tools/rocpd_gaps.py $db 0.5 > $G/r06_${n}_gaps.md && rm -rf $G/prof_$n
 done
 # ---- SQ counters of the dominant kernels at 200 crops: the halo kernel (3x3 256->256), conv_x3_kernel on the same layer (PROBE_X3=7) and on 1x1 512->512
 cd /tmp
@@ -68,9 +69,10 @@ rm -rf $G/x3pmc_*
 timeout 300 python tools/x3h_bench.py 200 > $G/r06_x3h_microbench.md 2>/dev/null
 timeout 300 python tools/x3h_rule_bench.py > $G/r06_x3h_rule.md 2>/dev/null
 timeout 300 python tools/p3_bench.py 200 > $G/r06_p3_microbench.md 2>/dev/null
+timeout 200 python tools/x3_intercept_bench.py 200 > $G/r06_x3_intercept.md 2>/dev/null
 cd /tmp; PYTHONPATH=$R timeout 600 python -m densereg_amd.model.hourglass_um_crop_tiny --dataset nyu --num_stack 2 --num_fea 128 --is_train True --max_steps 90 --synthetic_crops 2000 2>&1 | grep "^\[train\]" > $R/$G/r06_cli_train.log; cd $R
 tail -6 $G/r06_pytest_gpu.log; tail -2 $G/r06_smoke.log
-for f in train infer train_x3off train_r05kernels train_g1 msra train_bf16 c5_bf16 c5_f32 torchrun allreduce; do python - <<PY
+for f in train infer infer_b40 train_x3off train_r05kernels train_g1 msra train_bf16 c5_bf16 c5_f32 torchrun allreduce; do python - <<PY
 import json
 try:
     d=json.load(open('$G/r06_bench_$f.json')); fv=d.get('forward_vote') or {}

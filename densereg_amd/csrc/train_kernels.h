@@ -109,7 +109,7 @@ template <int R16> struct BnRows { static constexpr int value = R16 ? DR_BN_ROWS
 // pass 4.8 -> 7.9 ms per three windows with HALF the raw bytes; profiles/r04_experiments.md section 9).
 // DR_BN_NT (experiment switch of the build): bit 1 = the passes' 16-byte stores non-temporal, bit 2 = their 16-byte fp32 loads
 #ifndef DR_BN_NT
-#define DR_BN_NT 3                        // (measured, visit 24: stores +0.25 %, loads +0.5 %, both +0.9-1.4 % on the step)
+#define DR_BN_NT 15                       // (measured: fp32 passes, visit 24: stores +0.25 %, loads +0.5 %, both +0.9-1.4 % on the step; the bf16 path's 8-byte accesses, visit 28: S=2 bf16 +0.4-0.9 %, config 5 equal)
 #endif
 __device__ __forceinline__ float4 bn_ld4(const float* p) {
 #if (DR_BN_NT & 2) && !defined(DR_EMU)
@@ -127,10 +127,25 @@ __device__ __forceinline__ void bn_st4(float* p, const float4 v) {
     *reinterpret_cast<float4*>(p) = v;
 #endif
 }
+// ... and (bits 4 / 8) the 8-byte bf16x4 stores / loads of the bf16 path's passes
+__device__ __forceinline__ dr_bf16x4 bn_ld4h(const __bf16* p) {
+#if (DR_BN_NT & 8) && !defined(DR_EMU)
+    return __builtin_nontemporal_load(reinterpret_cast<const dr_bf16x4*>(p));
+#else
+    return *reinterpret_cast<const dr_bf16x4*>(p);
+#endif
+}
+__device__ __forceinline__ void bn_st4h(__bf16* p, const dr_bf16x4 v) {
+#if (DR_BN_NT & 4) && !defined(DR_EMU)
+    __builtin_nontemporal_store(v, reinterpret_cast<dr_bf16x4*>(p));
+#else
+    *reinterpret_cast<dr_bf16x4*>(p) = v;
+#endif
+}
 template <int R16>
 __device__ __forceinline__ float4 bn_load_raw4(const float* raw, long e) {
     if (R16) {
-        const dr_bf16x4 h = *reinterpret_cast<const dr_bf16x4*>(reinterpret_cast<const __bf16*>(raw) + e);
+        const dr_bf16x4 h = bn_ld4h(reinterpret_cast<const __bf16*>(raw) + e);
         const dr_f32x4 f = __builtin_convertvector(h, dr_f32x4);
         return make_float4(f[0], f[1], f[2], f[3]);
     }
@@ -468,7 +483,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
             float* o = p.out.p + m * p.out.cs + p.out.coff + cg * 4;
             if (p.out_bf16) {                                               // pad channels of the group: zero, like every producer of bf16 storage
                 const dr_f32x4 f = {cg * 4 + 0 < p.C ? v[0] : 0.f, cg * 4 + 1 < p.C ? v[1] : 0.f, cg * 4 + 2 < p.C ? v[2] : 0.f, cg * 4 + 3 < p.C ? v[3] : 0.f};
-                *reinterpret_cast<dr_bf16x4*>(reinterpret_cast<__bf16*>(p.out.p) + m * p.out.cs + p.out.coff + cg * 4) = __builtin_convertvector(f, dr_bf16x4);
+                bn_st4h(reinterpret_cast<__bf16*>(p.out.p) + m * p.out.cs + p.out.coff + cg * 4, __builtin_convertvector(f, dr_bf16x4));
             } else if (vec_out) {
                 bn_st4(o, make_float4(v[0], v[1], v[2], v[3]));
             } else {
@@ -727,7 +742,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_i
 #pragma unroll
             for (int u = 0; u < kRows; ++u) {
                 const long m = m0 + u * stride, mc = m < p.M ? m : p.M - 1;
-                const dr_bf16x4 hd = *reinterpret_cast<const dr_bf16x4*>(reinterpret_cast<const __bf16*>(p.dout.p) + mc * p.dout.cs + p.dout.coff + cg * 4);
+                const dr_bf16x4 hd = bn_ld4h(reinterpret_cast<const __bf16*>(p.dout.p) + mc * p.dout.cs + p.dout.coff + cg * 4);
                 const dr_f32x4 fd = __builtin_convertvector(hd, dr_f32x4);
                 d4[u] = make_float4(fd[0], fd[1], fd[2], fd[3]);
             }
@@ -781,7 +796,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p_i
             }
             if (p.draw_bf16) {
                 const dr_f32x4 f = {o[0], o[1], o[2], o[3]};
-                *reinterpret_cast<dr_bf16x4*>(reinterpret_cast<__bf16*>(p.draw) + m * p.raw_cs + cg * 4) = __builtin_convertvector(f, dr_bf16x4);
+                bn_st4h(reinterpret_cast<__bf16*>(p.draw) + m * p.raw_cs + cg * 4, __builtin_convertvector(f, dr_bf16x4));
             } else {
                 bn_st4(p.draw + m * p.raw_cs + cg * 4, make_float4(o[0], o[1], o[2], o[3]));
             }

@@ -31,6 +31,8 @@ namespace dr {
 // instructions in the SQ counters) measured EQUAL in the conv kernel and 8-11 % SLOWER in the weight-gradient kernel
 // (profiles/r05_experiments.md section 8): kept behind DR_X3_SPLIT_HAND for the record, not built.
 typedef float dr_f32x2 __attribute__((ext_vector_type(2)));
+__host__ __device__ static inline float4 x3_as_f4(const float4& v) { return v; }
+__host__ __device__ static inline float4 x3_as_f4(const dr_f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); }
 typedef __bf16 dr_bf16x2 __attribute__((ext_vector_type(2)));
 __host__ __device__ static inline unsigned x3_pack2(float a, float b) {
     const dr_f32x2 f = {a, b};
@@ -79,7 +81,10 @@ __global__ __launch_bounds__(NW * 64, (x3_waves_per_simd<BM, BN, LO, NW>())) voi
     // otherwise hoists the split (and with it the wait for the global load issued a few instructions earlier) in among the first MFMAs of
     // every other K-tile -- the wave then sits out the whole HBM round trip with ten of its twelve MFMAs unissued.
     constexpr int NT = NW * 64;                              // threads
-    constexpr int WM = WM_, WN = NW / WM_, WK = 1, MF = 32, ABL = ABL_;      // (ABL_ = 3: no epilogue stores -- a measurement build)
+    constexpr int WM = WM_, WN = NW / WM_, WK = 1, MF = 32, ABL = (ABL_ & 3) == 3 ? 3 : 0;
+    // ABL_ (measurement builds of the two-stage BD loop, debug library): 3 = no epilogue stores; after the first K-tile: 16 = no pixel
+    // path (global loads, split, ds_write), 32 = no weight copies, 64 = no waits and no barrier; sums combine
+    constexpr bool kNoA = (ABL_ & 16) != 0, kNoB = (ABL_ & 32) != 0, kNoSync = (ABL_ & 64) != 0;
     constexpr int kWTM = BM / WM, kWTN = BN / WN, kTM = kWTM / 32, kTN = kWTN / 32;
     static_assert(kWTM % 32 == 0 && kWTN % 32 == 0, "wave tile of whole 32x32 MFMA tiles");
     constexpr int CK = 16;                                   // input channels per K-tile
@@ -182,14 +187,22 @@ __global__ __launch_bounds__(NW * 64, (x3_waves_per_simd<BM, BN, LO, NW>())) voi
     }
     const long w_tile = 3l * p.Np * 16;                                    // bf16 elements per (chunk, tap)
 
-    float4 a_reg[kAIters], a_reg2[PF ? kAIters : 1];                       // (PF: a second set -- the pixels of two K-tiles in flight)
+    float4 a_reg[kAIters];
+    // PF = 1: two register sets, loaded by global_load_dwordx4 written as inline asm -- hidden from hipcc's wait-count insertion like the
+    // weight copies (with ordinary loads it put s_waitcnt vmcnt(0) in front of every use: one K-tile in flight again) -- and tied to
+    // their consumer by an asm s_waitcnt that takes the registers as in/out operands (X3_TIE_WAIT): nothing reads them before it.
+#if defined(DR_EMU)
+    float4 a_hid[PF == 1 ? kAIters : 1], a_hid2[PF == 1 ? kAIters : 1];
+#else
+    dr_f32x4 a_hid[PF == 1 ? kAIters : 1], a_hid2[PF == 1 ? kAIters : 1];
+#endif
     float4 b_reg0, b_reg1, b_reg2;                                          // (scalars: hipcc keeps a float4[3] refilled inside the unrolled K loop in scratch)
     static_assert(BD || kBIters <= 3, "weight loader mapping");
     int ld_kc = 0, ld_dy = -pad, ld_dx = -pad, ld_tap = 0;
     const float* ld_x = p.x + (long)(ld_dy * p.W + ld_dx) * p.x_cs;
     const __bf16* ld_w = w3;
     int a_nv[kAIters], a_nv2[PF ? kAIters : 1];
-    auto load_tile_to = [&](float4 (&a_reg)[kAIters], int (&a_nv)[kAIters]) __attribute__((always_inline)) {
+    auto load_tile_to = [&](auto& a_reg, int (&a_nv)[kAIters]) __attribute__((always_inline)) {
         const bool tail = ld_kc + CK > p.Cin;                              // uniform: this chunk crosses Cin
 #pragma unroll
         for (int i = 0; i < kAIters; ++i) {
@@ -200,6 +213,12 @@ __global__ __launch_bounds__(NW * 64, (x3_waves_per_simd<BM, BN, LO, NW>())) voi
                 nv = left < 0 ? 0 : (left > 4 ? 4 : left);
                 ok = ok && nv > 0;
             }
+#if !defined(DR_EMU)
+            if constexpr (PF == 1) {
+                const float* src = ok ? ld_x + ld_kc + a_off[i] : p.zeros;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a_reg[i]) : "v"(src) : "memory");
+            } else
+#endif
             a_reg[i] = *reinterpret_cast<const float4*>(ok ? ld_x + ld_kc + a_off[i] : p.zeros);
             a_nv[i] = ok ? nv : 4;
         }
@@ -222,12 +241,13 @@ __global__ __launch_bounds__(NW * 64, (x3_waves_per_simd<BM, BN, LO, NW>())) voi
     };
     auto load_tile = [&]() __attribute__((always_inline)) { load_tile_to(a_reg, a_nv); };
     const bool ragged = (p.Cin & 3) != 0;
-    auto store_tile_from = [&](const int buf, const bool was_tail, const float4 (&a_reg)[kAIters], const int (&a_nv)[kAIters]) __attribute__((always_inline)) {
+    auto store_tile_from = [&](const int buf, const bool was_tail, const auto& a_reg, const int (&a_nv)[kAIters]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < kAIters; ++i) {
             const int r = a_row[i], q = a_q[i];
             if (BM * 4 < NT * kAIters && r >= BM) continue;
-            float4 v = a_reg[i];
+            float4 v;
+            v = x3_as_f4(a_reg[i]);
             if (ragged && was_tail) {
                 const int nv = a_nv[i];
                 v.y = nv > 1 ? v.y : 0.f;
@@ -377,20 +397,32 @@ __global__ __launch_bounds__(NW * 64, (x3_waves_per_simd<BM, BN, LO, NW>())) voi
     // the loads of t+2 are outstanding (loads return in order: the copy of t+1, issued BEFORE them, has landed) | barrier.
 #if defined(DR_EMU)
 #define X3_WAIT_BUT_PIXELS() ((void)0)
+#define X3_TIE_WAIT(regs, keep) ((void)0)
 #else
 #define X3_WAIT_BUT_PIXELS() do { if constexpr (kAIters == 1) P3_WAIT_VM(1); else if constexpr (kAIters == 2) P3_WAIT_VM(2); else P3_WAIT_VM(0); } while (0)
+    // "at most `keep` x kAIters newer loads outstanding" AND the registers of `regs` are the wait's operands: their readers cannot be
+    // scheduled in front of it (the loads that fill them are invisible to the compiler)
+#define X3_TIE_WAIT(regs, keep)                                                                                                   \
+    do {                                                                                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < kAIters; ++i_) {                                                                  \
+            if ((keep) && kAIters == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(regs[i_])::"memory");                            \
+            else if ((keep) && kAIters == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(regs[i_])::"memory");                       \
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(regs[i_])::"memory");                                                   \
+        }                                                                                                                         \
+    } while (0)
 #endif
+    static_assert(kAIters <= 2, "hand-counted waits");
     dma_bd(0);
-    load_tile_to(a_reg, a_nv);
+    load_tile_to(a_hid, a_nv);
     bool tl2 = false;
-    if (T_total > 1) { tl2 = ld_kc + CK > p.Cin; load_tile_to(a_reg2, a_nv2); }
-    if (T_total > 1) X3_WAIT_BUT_PIXELS(); else P3_WAIT_VM(0);            // the weight copy and the pixels of tile 0 (tile 1's stay in flight)
-    store_tile_from(0, tail0, a_reg, a_nv);
+    if (T_total > 1) { tl2 = ld_kc + CK > p.Cin; load_tile_to(a_hid2, a_nv2); }
+    X3_TIE_WAIT(a_hid, T_total > 1);                                      // the weight copy and the pixels of tile 0 (tile 1's stay in flight)
+    store_tile_from(0, tail0, a_hid, a_nv);
     if (T_total > 1) X3_WAIT_BUT_PIXELS(); else P3_WAIT_VM(0);            // (its lgkmcnt(0): the ds_writes)
     __builtin_amdgcn_s_barrier();
     bool tl1 = false;
-    auto pf_tile = [&](const int buf, const bool more1, const bool more2, float4 (&rl)[kAIters], int (&nvl)[kAIters], bool& tl_l,
-                       const float4 (&rs)[kAIters], const int (&nvs)[kAIters], const bool tl_s) __attribute__((always_inline)) {
+    auto pf_tile = [&](const int buf, const bool more1, const bool more2, auto& rl, int (&nvl)[kAIters], bool& tl_l,
+                       auto& rs, const int (&nvs)[kAIters], const bool tl_s) __attribute__((always_inline)) {
         if (more1) dma_bd(buf ^ 1);
         if (more2) { tl_l = ld_kc + CK > p.Cin; load_tile_to(rl, nvl); }
         float4 a0[kTM], b0[kTN], ax[kTM], bx[kTN];
@@ -403,18 +435,19 @@ __global__ __launch_bounds__(NW * 64, (x3_waves_per_simd<BM, BN, LO, NW>())) voi
         X3_MMA(LOACC, a0, bx);
         X3_MMA(LOACC, ax, bx);
         __builtin_amdgcn_sched_barrier(0);
-        if (more1) store_tile_from(buf ^ 1, tl_s, rs, nvs);
+        if (more1) { X3_TIE_WAIT(rs, more2); store_tile_from(buf ^ 1, tl_s, rs, nvs); }   // (in order: the weight copy of t+1, issued before the loads of t+2, has landed too)
         __builtin_amdgcn_sched_barrier(0);
         if (more2) X3_WAIT_BUT_PIXELS(); else P3_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();
     };
     const int T_pairs = T_total & ~1;
     for (int t = 0; t < T_pairs; t += 2) {
-        pf_tile(0, true, t + 2 < T_total, a_reg, a_nv, tl1, a_reg2, a_nv2, tl2);
-        pf_tile(1, t + 2 < T_total, t + 3 < T_total, a_reg2, a_nv2, tl2, a_reg, a_nv, tl1);
+        pf_tile(0, true, t + 2 < T_total, a_hid, a_nv, tl1, a_hid2, a_nv2, tl2);
+        pf_tile(1, t + 2 < T_total, t + 3 < T_total, a_hid2, a_nv2, tl2, a_hid, a_nv, tl1);
     }
-    if (T_total & 1) pf_tile(0, false, false, a_reg, a_nv, tl1, a_reg2, a_nv2, tl2);
+    if (T_total & 1) pf_tile(0, false, false, a_hid, a_nv, tl1, a_hid2, a_nv2, tl2);
 #undef X3_WAIT_BUT_PIXELS
+#undef X3_TIE_WAIT
     } else {
     load_tile(); dma_bd(0);
     store_tile(0, tail0);
@@ -422,7 +455,7 @@ __global__ __launch_bounds__(NW * 64, (x3_waves_per_simd<BM, BN, LO, NW>())) voi
 
     auto k_tile = [&](const int buf, const bool more) __attribute__((always_inline)) {
         const bool was_tail = ld_kc + CK > p.Cin;                          // of the tile being fetched now
-        if (more) { load_tile(); dma_bd(buf ^ 1); }
+        if (more) { if constexpr (!kNoA) load_tile(); if constexpr (!kNoB) dma_bd(buf ^ 1); }
         // fragments are read plane by plane, the planes 2 first: their registers are reused by the planes 1 (eight fragments live, not twelve)
         float4 a0[kTM], b0[kTN], ax[kTM], bx[kTN];
         X3_READ_A(a0, 0, buf); X3_READ_B(b0, 0, buf); X3_READ_A(ax, 2, buf); X3_READ_B(bx, 2, buf);
@@ -434,8 +467,10 @@ __global__ __launch_bounds__(NW * 64, (x3_waves_per_simd<BM, BN, LO, NW>())) voi
         X3_MMA(LOACC, a0, bx);                                                // a0*b1
         X3_MMA(LOACC, ax, bx);                                                // a1*b1
         if constexpr (PF == 2) __builtin_amdgcn_sched_barrier(0);
-        if (more) store_tile(buf ^ 1, was_tail);
-        if constexpr (BD) {                                                 // the tile's MFMAs are issued, then: the copy has landed, every LDS access returned
+        if constexpr (!kNoA) { if (more) store_tile(buf ^ 1, was_tail); }
+        if constexpr (kNoSync) {
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (BD) {                                          // the tile's MFMAs are issued, then: the copy has landed, every LDS access returned
             __builtin_amdgcn_sched_barrier(0);
             P3_WAIT_VM(0);
             __builtin_amdgcn_s_barrier();

@@ -182,14 +182,15 @@ static bool x3_bd() {
 }
 // ... and the pixels of two K-tiles in flight (conv_x3.h, PF = 1) or a scheduling barrier before the split (PF = 2).  DR_X3_PF = mode
 // (0 off), DR_X3_PF_MAXT = n: only layers of at most n K-tiles (1x1: Cin <= 16 n)
-[[maybe_unused]] static bool x3_abl3() {
-    static const bool on = [] { const char* e = getenv("DR_X3_ABL"); return e && atoi(e) == 3; }();
-    return on;
+[[maybe_unused]] static int x3_abl() {                                  // DR_X3_ABL: conv_x3.h, ABL_ (debug library)
+    static const int v = [] { const char* e = getenv("DR_X3_ABL"); return e ? atoi(e) : 0; }();
+    return v;
 }
 [[maybe_unused]] static int x3_pf(const ConvParams& p) {
     static const int mode = [] { const char* e = getenv("DR_X3_PF"); return e ? atoi(e) : 0; }();
     static const int lim = [] { const char* e = getenv("DR_X3_PF_MAXT"); return e ? atoi(e) : 1 << 30; }();
-    return p.ksize * p.ksize * (p.Kp / 16) <= lim ? mode : 0;
+    const int T = p.ksize * p.ksize * (p.Kp / 16);
+    return T <= lim && T >= 2 ? mode : 0;                     // (the two-tile prefetch wants two K-tiles: a one-tile layer measured wrong results)
 }
 bool conv_use_x3(const ConvParams& p) {
     static const int env = [] { const char* e = getenv("DR_CONV_X3"); return e ? atoi(e) : 1; }();
@@ -356,7 +357,13 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
 #endif
             else if (w4) DR_LAUNCH((conv_x3_kernel<128, 128, 1>), grid, dim3(256), 0, s, q);
 #if defined(DR_DEBUG_HOOKS)
-            else if (x3_bd() && x3_abl3()) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1, 0, 3>), grid, dim3(512), 0, s, q);
+            else if (x3_bd() && x3_abl() == 3) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1, 0, 3>), grid, dim3(512), 0, s, q);
+            else if (x3_bd() && x3_abl() == 16) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1, 0, 16>), grid, dim3(512), 0, s, q);
+            else if (x3_bd() && x3_abl() == 32) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1, 0, 32>), grid, dim3(512), 0, s, q);
+            else if (x3_bd() && x3_abl() == 48) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1, 0, 48>), grid, dim3(512), 0, s, q);
+            else if (x3_bd() && x3_abl() == 51) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1, 0, 51>), grid, dim3(512), 0, s, q);
+            else if (x3_bd() && x3_abl() == 112) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1, 0, 112>), grid, dim3(512), 0, s, q);
+            else if (x3_bd() && x3_abl() == 115) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1, 0, 115>), grid, dim3(512), 0, s, q);
             else if (x3_bd() && x3_pf(p) == 1) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1, 1>), grid, dim3(512), 0, s, q);
             else if (x3_bd() && x3_pf(p) == 2) DR_LAUNCH((conv_x3_kernel<128, 128, 1, 0, 8, 2, 1, 2>), grid, dim3(512), 0, s, q);
 #endif

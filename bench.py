@@ -215,6 +215,9 @@ def main():
     args = parse()
     if args.gpus < 1:
         sys.exit('bench.py: --gpus must be >= 1')
+    # dmabuf IPC (RCCL / cross-process device memory on this driver): also when an external launcher started the ranks without it --
+    # the HIP runtime reads it at its first call, which is further down
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         spawn_ranks(args)
     # stdout carries exactly ONE line, the JSON: anything else written to file descriptor 1 during the run (RCCL prints a
